@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the smafa scan engine on MI355X.
+
+Metric (BASELINE.json): query seqs/sec (+ DB residues/sec) vs the HBM roofline, 10M x 60-aa DB, d <= 5.
+A "step" = one pass of the hot path over one batch: every query of the batch (default 10 000 per GPU)
+scanned against the whole resident subject store, qualifying rows appended on the device, and — when
+more than one GPU takes part — the per-rank row lists gathered on rank 0 over RCCL.  The packed subject
+block and the packed query batch are resident in HBM before the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N = 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Scaling is weak: the DB is replicated, every rank scans its own query
+shard of fixed size.  `roofline` is for the dominant kernel (scan_kernel), timed with HIP events on the
+launch stream; `cpu_baseline` is the oracle's single-thread port of the reference's per-query loop on a
+bounded sample (the only place bench.py touches oracle/, besides the post-run result check).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz (one wave64 VALU op = 2 cycles)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--db-rows", type=int, default=10_000_000)
+    ap.add_argument("--queries", type=int, default=10_000, help="queries per GPU per step")
+    ap.add_argument("--seq-len", type=int, default=60)
+    ap.add_argument("--alphabet", choices=["aa", "nt"], default="aa")
+    ap.add_argument("--max-div", type=int, default=5)
+    ap.add_argument("--query-block", type=int, default=0, help="queries per workgroup pass (0 = automatic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+
+    import smafa_amd
+    from smafa_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available() or smafa_amd.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the scan engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    alphabet = smafa_amd.ALPHABET_AA if args.alphabet == "aa" else smafa_amd.ALPHABET_NT
+    L, N, Q, D = args.seq_len, args.db_rows, args.queries, args.max_div
+    max_subs = 10 if alphabet == smafa_amd.ALPHABET_AA else 6
+
+    # ---- synthetic workload: identical DB on every rank, disjoint query shards
+    t_gen = time.time()
+    subj = synth.subjects(N, L, alphabet, seed=1)
+    all_q, planted_row, planted_subs = synth.queries(subj, Q * world, alphabet, seed=3, max_subs=max_subs)
+    q_lo = rank * Q
+    my_q = all_q[q_lo:q_lo + Q]
+    t_gen = time.time() - t_gen
+
+    # ---- residency: pack + upload once
+    t_up = time.time()
+    store = smafa_amd.SubjectStore(L, alphabet, local_rank)
+    store.push(subj)
+    qset = smafa_amd.QuerySet(store, my_q)
+    t_up = time.time() - t_up
+    info = store.info()
+    if args.query_block:
+        store.set_query_block(args.query_block)
+    stream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream shared by torch and the library
+    torch.cuda.set_stream(stream)
+    store.set_stream(stream.cuda_stream)  # launches go to torch's stream: torch events see them
+
+    cap = max(4 * Q, 1 << 16)
+    d_hits = torch.zeros(cap * 3, dtype=torch.int32, device=dev)
+    d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+    if world > 1:
+        counts_all = torch.zeros(world, dtype=torch.int64, device=dev)
+        gathered = torch.zeros(world * cap * 3, dtype=torch.int32, device=dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i_timed: int | None) -> None:
+        if i_timed is not None:
+            ev[i_timed][0].record(stream)
+        store.scan_launch(qset, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
+        if i_timed is not None:
+            ev[i_timed][1].record(stream)
+        if world > 1:  # RCCL gather of the row lists on rank 0 (all_gather keeps every rank symmetric)
+            dist.all_gather_into_tensor(counts_all, d_count)
+            dist.all_gather_into_tensor(gathered, d_hits)
+
+    def fence() -> None:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(None)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms_avg = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+
+    # ---- result check (outside the timed region): planted rows present, every row's distance recomputed
+    n_rows = int(d_count.item())
+    rows = d_hits[: 3 * min(n_rows, cap)].cpu().numpy().view(np.uint32).reshape(-1, 3)
+    ok = n_rows <= cap
+    recomputed = (subj[rows[:, 1]] != my_q[rows[:, 0]]).sum(axis=1)
+    ok = ok and bool((recomputed == rows[:, 2]).all()) and bool((rows[:, 2] <= D).all())
+    have = set(zip(rows[:, 0].tolist(), rows[:, 1].tolist()))
+    for qi in range(Q):
+        if planted_subs[q_lo + qi] <= D and (qi, int(planted_row[q_lo + qi])) not in have:
+            ok = False
+            break
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+
+    # ---- stream mode: ONE query per pass — the HBM-bound form of the same kernel (north_star's literal
+    #      "broadcast each query against all subjects"); reported beside the batched roofline
+    stream_info = None
+    if rank == 0:
+        one = smafa_amd.QuerySet(store, my_q[:1])
+        for _ in range(3):
+            store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        e0.record(stream)
+        for _ in range(reps):
+            store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps  # includes the tiny threshold-fill + counter-reset launches
+        stream_info = {
+            "ms_per_query": ms,
+            "stored_GBs": info.hbm_bytes / ms / 1e6,
+            "algorithmic_GBs": N * L / ms / 1e6,
+            "frac_of_peak_stored": info.hbm_bytes / ms / 1e6 / HBM_PEAK_GBS,
+            "note": "one query per DB pass; stored = bit-plane bytes actually streamed (%d B/subject), "
+                    "algorithmic = %d B/subject" % (info.bytes_per_subject, L),
+        }
+        one.close()
+
+    # ---- CPU baseline: the oracle's port of the reference's per-query loop, one thread, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+
+        oracle.build()
+        tq = time.perf_counter()
+        oracle.bench_besthit_codes(subj, my_q[:2], D)
+        per_q = (time.perf_counter() - tq) / 2
+        n_sample = int(max(4, min(Q, args.cpu_seconds / max(per_q, 1e-6))))
+        tq = time.perf_counter()
+        oracle.bench_besthit_codes(subj, my_q[:n_sample], D)
+        dt = time.perf_counter() - tq
+        cpu = {
+            "value": n_sample / dt, "unit": "query seqs/s", "cores": 1, "kind": "port",
+            "sample": "first %d queries of the same batch against the same %d x %d %s store; oracle C port of "
+                      "src/lib.rs:238 (distances) + :298 (min) + :307 (equality pass), gcc -O3, 1 thread, "
+                      "contiguous store" % (n_sample, N, L, args.alphabet),
+            "host_cores_available": os.cpu_count(),
+        }
+
+    if rank == 0:
+        q_total = Q * world
+        value = q_total * args.steps / elapsed
+        pairs_per_launch = Q * N
+        alg_bytes = pairs_per_launch * L  # B_s = L x 8 bits / 8 = 60 B per (query, subject)
+        achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
+        ops_per_pair = (info.planes * info.words_per_plane + info.words_per_plane + 0.75)
+        out = {
+            "metric": "query seqs/sec (DB residues/sec in `residues_per_s`) vs HBM roofline, %dM x %d%s DB, d<=%d"
+                      % (N // 1_000_000, L, args.alphabet, D),
+            "value": value,
+            "unit": "query seqs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%d x %d %s subject store (uniform letters, 1%% duplicate rows, seed 1) replicated per GPU; "
+                            "%d planted queries per GPU per step (0..%d substitutions, seed 3); max-divergence %d"
+                            % (N, L, args.alphabet, Q, max_subs, D),
+                "db_rows": N, "seq_len": L, "alphabet": args.alphabet, "queries_per_gpu": Q, "max_divergence": D,
+                "parallelism": "query shards x%d, DB replicated, RCCL all_gather of row lists" % world,
+            },
+            "residues_per_s": value * N * L,
+            "pairs_per_s": value * N,
+            "rows_per_step": n_rows,
+            "verified": ok,
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "smafa::scan_kernel<%d,%d>" % (info.planes, info.words_per_plane),
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms_avg": kernel_ms_avg,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "algorithmic bytes = queries x subjects x %d B (SURVEY 8d). The kernel keeps a 1024-subject "
+                        "tile in registers and walks a whole query block over it, so the store is streamed from HBM "
+                        "once per query block, not once per query: frac > 1 is register-level reuse, NOT HBM "
+                        "efficiency. The real ceiling of this kernel is VALU issue (see `valu`); the HBM-bound form "
+                        "(one query per pass) is in `stream`." % L,
+                "valu": {
+                    "lane_ops_per_pair": ops_per_pair,
+                    "achieved_lane_ops": pairs_per_launch * ops_per_pair / (kernel_ms_avg * 1e-3),
+                    "peak_lane_ops": VALU_PEAK_LANE_OPS,
+                    "frac": pairs_per_launch * ops_per_pair / (kernel_ms_avg * 1e-3) / VALU_PEAK_LANE_OPS,
+                },
+                "stored_bytes_per_subject": int(info.bytes_per_subject),
+            },
+            "stream": stream_info,
+            "cpu_baseline": cpu,
+            "setup_s": {"generate": t_gen, "pack_upload": t_up},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+/*
+ * smafa_amd.h — C ABI of the MI355X-native smafa scan engine (libsmafa_amd.so).
+ *
+ * Drop-in boundary for the ONE hot path of wwood/smafa v0.8.0: the fixed-length
+ * Hamming scan behind `smafa query` and `smafa cluster`.  The reference has no FFI
+ * of its own; each entry point below names the reference code it replaces
+ * (file:line relative to the reference tree).  Plain pointers and sizes only — a
+ * Rust host binds these 1:1 (see INTEGRATION.md for the `extern "C"` block).
+ *
+ * Conventions
+ *  - every function returns SMAFA_OK (0) or a negative SMAFA_ERR_* code; the text
+ *    of the failure (the reference's panic message where there is one) is kept
+ *    per thread in smafa_last_error().  Nothing aborts or throws across the ABI.
+ *  - sequences cross the boundary as CODE BYTES, one byte per column, row-major
+ *    (n rows of seq_len columns), produced by smafa_encode().
+ *  - one handle = one owner thread at a time (the reference is single-threaded).
+ *  - there is NO CPU fallback: without a HIP device every scan entry point fails
+ *    with SMAFA_ERR_DEVICE.
+ */
+#ifndef SMAFA_AMD_H
+#define SMAFA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMAFA_OK 0
+#define SMAFA_ERR_INVALID (-1)  /* bad argument */
+#define SMAFA_ERR_DEVICE (-2)   /* no HIP device / HIP runtime failure */
+#define SMAFA_ERR_CAPACITY (-3) /* caller's hit buffer too small: *n_out = rows needed, grow and retry */
+#define SMAFA_ERR_IO (-4)       /* file could not be read / written */
+#define SMAFA_ERR_FORMAT (-5)   /* malformed FASTX / DB file, unsupported DB version */
+#define SMAFA_ERR_PANIC (-6)    /* input on which the reference panics (message preserved) */
+
+#define SMAFA_ALPHABET_NT 0 /* A C G T/U N — classes of BYTE_LUT, src/lib.rs:171-178; codes 0..4 */
+#define SMAFA_ALPHABET_AA 1 /* build-defined extension: A-Z * - (case-folded), codes 0..27; not in the reference */
+
+#define SMAFA_NONE UINT32_MAX /* "option absent" for max_div / max_num_hits / limit_per_sequence */
+
+#define SMAFA_DB_VERSION 2u /* CURRENT_DB_VERSION, src/lib.rs:18 */
+
+typedef struct smafa_db smafa_db;     /* subject store resident in HBM — WindowSet, src/lib.rs:54-60 */
+typedef struct smafa_qset smafa_qset; /* a packed query batch resident in HBM */
+
+/* one scan result row: the (query_number, i, distance) of src/lib.rs:292 / :310 */
+typedef struct {
+    uint32_t query;
+    uint32_t subject;
+    uint32_t dist;
+} smafa_hit;
+
+typedef struct {
+    uint64_t n_subjects;
+    uint32_t seq_len;
+    int32_t alphabet;
+    int32_t device;
+    uint32_t planes;          /* bit-planes per symbol: 3 (NT) or 5 (AA) */
+    uint32_t words_per_plane; /* ceil(seq_len / 32) */
+    uint64_t hbm_bytes;       /* bytes of the packed subject block in HBM */
+    uint64_t bytes_per_subject;
+} smafa_db_info_t;
+
+/* ------------------------------------------------------------------ library */
+const char *smafa_last_error(void);
+int smafa_device_count(void); /* 0 when no MI355X is visible; never fails */
+
+/* ----------------------------------------------------------------- encoding */
+/* Replaces create_lut/BYTE_LUT/encode_single (src/lib.rs:167-196) and the per-byte half of
+ * SeqEncodingLength::from_bytes (src/lib.rs:29-52).  On a byte outside the alphabet returns
+ * SMAFA_ERR_PANIC and stores its offset in *bad_pos (the reference's panic at src/lib.rs:36-42). */
+int smafa_encode(int alphabet, const uint8_t *ascii, uint64_t len, uint8_t *codes, uint64_t *bad_pos);
+/* Replaces WindowSet::get_as_string (src/lib.rs:113-135): codes -> "ACGTN" (or the AA letters). */
+int smafa_decode(int alphabet, const uint8_t *codes, uint64_t len, char *out);
+
+/* ------------------------------------------------------------ subject store */
+/* WindowSet::new (src/lib.rs:63-69) on `device`; seq_len fixes the equal-length invariant of
+ * src/lib.rs:91-111 up front (the host checks lengths before it calls append). */
+int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len);
+/* push_encoding x n (src/lib.rs:91-111): packs n rows of code bytes into the HBM bit-plane block.
+ * The host buffer is borrowed for the call only. */
+int smafa_db_append(smafa_db *db, const uint8_t *codes, uint64_t n);
+int smafa_db_info(const smafa_db *db, smafa_db_info_t *info);
+/* Launch on a caller-owned HIP stream (hipStream_t as void*) instead of the handle's own; NULL restores it. */
+int smafa_db_set_stream(smafa_db *db, void *hip_stream);
+void smafa_db_destroy(smafa_db *db); /* NULL-safe */
+
+/* ---------------------------------------------------------------- the scan */
+/*
+ * Replaces WindowSet::get_distances (src/lib.rs:71-89) + the threshold half of the
+ * selection in query (src/lib.rs:241-315) / cluster (src/cluster.rs:51-68).
+ *
+ * Emits every (query, subject, dist) with
+ *      dist <= max_div                       (max_div = SMAFA_NONE: no bound)
+ *  and dist <= kth(query)                    (max_num_hits = k >= 1: kth = the k-th smallest
+ *                                             distance of that query over the whole store, ties
+ *                                             included — src/lib.rs:250-256; SMAFA_NONE/0: no bound)
+ * ordered by (query, dist, subject) — the reference's print order (src/lib.rs:243-250, 307-311).
+ * With k = 1 this is "all subjects at the minimum distance" (src/lib.rs:296-313) and also
+ * cluster's argmin with ties to the lowest index (src/cluster.rs:54-68: first row per query).
+ * The device may emit rows above kth(query) (its threshold only ever tightens); those are
+ * removed before this call returns.
+ * cap = capacity of `out` in rows.  If more rows qualify: SMAFA_ERR_CAPACITY, *n_out = rows needed.
+ */
+int smafa_scan_hits(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div,
+                    uint32_t max_num_hits, smafa_hit *out, uint64_t cap, uint64_t *n_out);
+
+/* The literal get_distances seam (src/lib.rs:71-89): all N distances of ONE query, as u32.
+ * Costs N*4 bytes over PCIe per query — for tests and debugging, not the production path. */
+int smafa_distances(smafa_db *db, const uint8_t *query_codes, uint32_t *distances);
+
+/* ---- device-resident batch form (what bench.py times; inputs already in HBM) ---- */
+int smafa_qset_create(smafa_qset **out, smafa_db *db, const uint8_t *query_codes, uint64_t n_queries);
+void smafa_qset_destroy(smafa_qset *qs);
+/*
+ * Asynchronous scan of a resident query set against the resident store on the handle's stream.
+ * d_hits: device buffer of cap smafa_hit rows (unordered on return); d_count: device uint64 that
+ * receives the number of qualifying rows (may exceed cap; only the first cap are stored).
+ * max_div / max_num_hits as in smafa_scan_hits, except that rows above kth(query) are NOT removed.
+ */
+int smafa_scan_launch(smafa_db *db, smafa_qset *qs, uint32_t max_div, uint32_t max_num_hits, void *d_hits,
+                      uint64_t cap, void *d_count);
+int smafa_sync(smafa_db *db);
+/* Device time in ms of the scan kernel(s) of the most recent smafa_scan_launch / smafa_scan_hits on
+ * this handle, from HIP events recorded on the launch stream; also how many kernel launches it took. */
+int smafa_last_scan_ms(smafa_db *db, float *ms, uint32_t *n_launches);
+/* Tuning knob: queries per workgroup pass (0 = automatic). */
+int smafa_set_query_block(smafa_db *db, uint32_t queries_per_block);
+
+/* -------------------------------------------------------- host-side selection */
+/*
+ * The row-selection rules of query (src/lib.rs:241-315) applied to a hit list already ordered by
+ * (query, dist, subject) that holds, per query, at least every subject within min(max_div, kth).
+ * subject_codes (n_subjects rows of seq_len) is needed only for limit_per_sequence (adjacent equal
+ * strings, src/lib.rs:269-289).  n_queries = number of queries the hit list covers (query ids
+ * 0..n_queries-1); a query with no hit at all while max_div is SMAFA_NONE means an empty store.
+ * Returns SMAFA_ERR_PANIC for the inputs the reference panics on (empty store, k = 0,
+ * limit_per_sequence without max_num_hits > 1).  Output rows are in print order.
+ */
+int smafa_select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint64_t n_subjects,
+                      const uint8_t *subject_codes, uint32_t seq_len, uint32_t max_div, uint32_t max_num_hits,
+                      uint32_t limit_per_sequence, smafa_hit *rows, uint64_t cap, uint64_t *n_rows);
+
+/* ------------------------------------------------------------------ DB file */
+/* Serialise / parse the reference's v2 DB file (postcard wire format of WindowSet,
+ * src/lib.rs:54-60,161-162,208-218).  NT only.  smafa_dbfile_write: codes -> file bytes identical to
+ * the reference's makedb.  smafa_dbfile_read: file -> malloc'd code rows (free with smafa_free);
+ * a version other than 2 fails with the reference's "Unsupported db file version" text.
+ * Version 3 is this build's extension container for amino-acid stores (alphabet byte + raw code rows). */
+int smafa_dbfile_write(const char *path, int alphabet, const uint8_t *codes, uint64_t n, uint32_t seq_len);
+int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t *n, uint32_t *seq_len);
+void smafa_free(void *p);
+
+/* ------------------------------------------- drivers: the crate's pub fns */
+/* makedb(subject_fasta, db_path) — src/lib.rs:137-165.  Host only (no GPU needed). */
+int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet);
+/* query(db_path, query_fasta, max_divergence, max_num_hits, limit_per_sequence) — src/lib.rs:198-325.
+ * Options use SMAFA_NONE for None.  TSV rows go to out_fd (the reference prints to stdout). */
+int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_divergence, uint32_t max_num_hits,
+                uint32_t limit_per_sequence, int out_fd, int device);
+/* cluster(input_fasta, max_divergence, print_stream) — src/cluster.rs:13-94. */
+int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet);
+/* count(paths) — src/lib.rs:378-398 (JSON to out_fd).  Host only. */
+int smafa_count(const char *const *paths, uint64_t n_paths, int out_fd);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,116 @@
+"""ctypes loader for libsmafa_amd.so (the C ABI of include/smafa_amd.h).
+
+The library is built in-tree by ``smafa_amd/csrc/Makefile`` (hipcc, gfx950).  There is no
+Python or CPU fallback: if the shared object is missing this module raises, and every scan
+entry point fails with SMAFA_ERR_DEVICE when no HIP device is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "lib", "libsmafa_amd.so")
+CLI_PATH = os.path.join(_HERE, "bin", "smafa")
+
+OK = 0
+ERR_INVALID, ERR_DEVICE, ERR_CAPACITY, ERR_IO, ERR_FORMAT, ERR_PANIC = -1, -2, -3, -4, -5, -6
+NONE = 0xFFFFFFFF
+ALPHABET_NT, ALPHABET_AA = 0, 1
+
+# every symbol include/smafa_amd.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "smafa_last_error", "smafa_device_count", "smafa_encode", "smafa_decode",
+    "smafa_db_create", "smafa_db_append", "smafa_db_info", "smafa_db_set_stream", "smafa_db_destroy",
+    "smafa_scan_hits", "smafa_distances", "smafa_qset_create", "smafa_qset_destroy", "smafa_scan_launch",
+    "smafa_sync", "smafa_last_scan_ms", "smafa_set_query_block", "smafa_select_rows",
+    "smafa_dbfile_write", "smafa_dbfile_read", "smafa_free",
+    "smafa_makedb", "smafa_query", "smafa_cluster", "smafa_count",
+]
+
+
+class Hit(C.Structure):
+    _fields_ = [("query", C.c_uint32), ("subject", C.c_uint32), ("dist", C.c_uint32)]
+
+
+class DbInfo(C.Structure):
+    _fields_ = [
+        ("n_subjects", C.c_uint64), ("seq_len", C.c_uint32), ("alphabet", C.c_int32), ("device", C.c_int32),
+        ("planes", C.c_uint32), ("words_per_plane", C.c_uint32), ("hbm_bytes", C.c_uint64),
+        ("bytes_per_subject", C.c_uint64),
+    ]
+
+
+def build(force: bool = False) -> None:
+    """Compile the HIP extension and the CLI for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j8"]
+    if force:
+        args.append("-B")
+    r = subprocess.run(args, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError("building libsmafa_amd.so failed:\n" + r.stdout + r.stderr)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C smafa_amd/csrc`). "
+            "smafa_amd has no CPU fallback.")
+    l = C.CDLL(LIB_PATH)
+    u8p, u32p, u64p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p
+    l.smafa_last_error.restype = C.c_char_p
+    l.smafa_device_count.restype = C.c_int
+    l.smafa_encode.argtypes = [C.c_int, vp, C.c_uint64, vp, u64p]
+    l.smafa_decode.argtypes = [C.c_int, vp, C.c_uint64, vp]
+    l.smafa_db_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_uint32]
+    l.smafa_db_append.argtypes = [vp, vp, C.c_uint64]
+    l.smafa_db_info.argtypes = [vp, C.POINTER(DbInfo)]
+    l.smafa_db_set_stream.argtypes = [vp, vp]
+    l.smafa_db_destroy.argtypes = [vp]
+    l.smafa_db_destroy.restype = None
+    l.smafa_scan_hits.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]
+    l.smafa_distances.argtypes = [vp, vp, vp]
+    l.smafa_qset_create.argtypes = [C.POINTER(vp), vp, vp, C.c_uint64]
+    l.smafa_qset_destroy.argtypes = [vp]
+    l.smafa_qset_destroy.restype = None
+    l.smafa_scan_launch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp]
+    l.smafa_sync.argtypes = [vp]
+    l.smafa_last_scan_ms.argtypes = [vp, C.POINTER(C.c_float), u32p]
+    l.smafa_set_query_block.argtypes = [vp, C.c_uint32]
+    l.smafa_select_rows.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, vp, C.c_uint64, u64p]
+    l.smafa_dbfile_write.argtypes = [C.c_char_p, C.c_int, vp, C.c_uint64, C.c_uint32]
+    l.smafa_dbfile_read.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(vp), u64p, u32p]
+    l.smafa_free.argtypes = [vp]
+    l.smafa_free.restype = None
+    l.smafa_makedb.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    l.smafa_query.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+    l.smafa_cluster.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_int]
+    l.smafa_count.argtypes = [C.POINTER(C.c_char_p), C.c_uint64, C.c_int]
+    _lib = l
+    return l
+
+
+class SmafaError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+class SmafaPanic(SmafaError):
+    """An input on which the reference panics (message preserved)."""
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        msg = lib().smafa_last_error().decode(errors="replace")
+        raise (SmafaPanic if rc == ERR_PANIC else SmafaError)(rc, msg)

@@ -1,0 +1,219 @@
+"""Host-side mirror of the reference crate's interface for the hot path.
+
+``makedb`` / ``query`` / ``cluster`` / ``count`` take the arguments of the reference's public
+functions (/root/reference/src/lib.rs:137,198,378; src/cluster.rs:13) — paths, and ``None`` for an
+absent option — and produce the same bytes.  ``SubjectStore`` is the ``WindowSet`` of
+src/lib.rs:54-135 living in HBM: ``push``/``get_distances``/``scan``.  Everything goes through the C
+ABI of libsmafa_amd.so; nothing here computes distances on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import ALPHABET_AA, ALPHABET_NT, NONE, Hit, SmafaError, SmafaPanic, check, lib
+
+HIT_DTYPE = np.dtype([("query", "<u4"), ("subject", "<u4"), ("dist", "<u4")])
+
+
+def _opt(v: Optional[int]) -> int:
+    return NONE if v is None else int(v)
+
+
+def device_count() -> int:
+    return lib().smafa_device_count()
+
+
+def encode(seq: bytes, alphabet: int = ALPHABET_NT) -> np.ndarray:
+    """ASCII -> code bytes (create_lut / from_bytes, src/lib.rs:29-52,167-196)."""
+    out = np.empty(len(seq), dtype=np.uint8)
+    bad = C.c_uint64(0)
+    check(lib().smafa_encode(alphabet, seq, len(seq), out.ctypes.data, C.byref(bad)))
+    return out
+
+
+def encode_rows(ascii_rows: np.ndarray, alphabet: int = ALPHABET_NT) -> np.ndarray:
+    a = np.ascontiguousarray(ascii_rows, dtype=np.uint8)
+    out = np.empty_like(a)
+    bad = C.c_uint64(0)
+    check(lib().smafa_encode(alphabet, a.ctypes.data, a.size, out.ctypes.data, C.byref(bad)))
+    return out
+
+
+def decode(codes: np.ndarray, alphabet: int = ALPHABET_NT) -> bytes:
+    """code bytes -> subject string (get_as_string, src/lib.rs:113-135)."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    out = C.create_string_buffer(codes.size)
+    check(lib().smafa_decode(alphabet, codes.ctypes.data, codes.size, out))
+    return out.raw
+
+
+class QuerySet:
+    """A packed query batch resident in HBM."""
+
+    def __init__(self, store: "SubjectStore", query_codes: np.ndarray):
+        q = np.ascontiguousarray(query_codes, dtype=np.uint8)
+        assert q.ndim == 2 and q.shape[1] == store.seq_len
+        self.n = q.shape[0]
+        self._h = C.c_void_p()
+        self._store = store
+        check(lib().smafa_qset_create(C.byref(self._h), store._h, q.ctypes.data, self.n))
+
+    def close(self):
+        if self._h:
+            lib().smafa_qset_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SubjectStore:
+    """WindowSet (src/lib.rs:54-135) resident in HBM as bit-planes."""
+
+    def __init__(self, seq_len: int, alphabet: int = ALPHABET_NT, device: int = 0):
+        self._h = C.c_void_p()
+        self.seq_len = int(seq_len)
+        self.alphabet = alphabet
+        check(lib().smafa_db_create(C.byref(self._h), device, alphabet, self.seq_len))
+
+    # push_encoding x n (src/lib.rs:91-111)
+    def push(self, codes: np.ndarray) -> None:
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        if c.ndim != 2 or c.shape[1] != self.seq_len:
+            raise SmafaPanic(_lib.ERR_PANIC, "WindowSet seq length is %d, got a new sequence of length %d"
+                             % (self.seq_len, c.shape[-1]))
+        check(lib().smafa_db_append(self._h, c.ctypes.data, c.shape[0]))
+
+    def __len__(self) -> int:
+        return int(self.info().n_subjects)
+
+    def info(self) -> _lib.DbInfo:
+        info = _lib.DbInfo()
+        check(lib().smafa_db_info(self._h, C.byref(info)))
+        return info
+
+    # get_distances (src/lib.rs:71-89)
+    def get_distances(self, query_codes: np.ndarray) -> np.ndarray:
+        q = np.ascontiguousarray(query_codes, dtype=np.uint8).reshape(-1)
+        if q.size != self.seq_len:
+            raise SmafaPanic(_lib.ERR_PANIC, "Cannot compute distances between seq of length %d and windows of lengths %d"
+                             % (q.size, self.seq_len))
+        out = np.zeros(len(self), dtype=np.uint32)
+        check(lib().smafa_distances(self._h, q.ctypes.data, out.ctypes.data))
+        return out
+
+    def scan(self, query_codes: np.ndarray, max_divergence: Optional[int] = None,
+             max_num_hits: Optional[int] = None) -> np.ndarray:
+        """All (query, subject, dist) rows within the bounds, ordered (query, dist, subject)."""
+        q = np.ascontiguousarray(query_codes, dtype=np.uint8)
+        assert q.ndim == 2 and q.shape[1] == self.seq_len
+        cap = 1 << 16
+        while True:
+            out = np.zeros(cap, dtype=HIT_DTYPE)
+            n_out = C.c_uint64(0)
+            rc = lib().smafa_scan_hits(self._h, q.ctypes.data, q.shape[0], _opt(max_divergence), _opt(max_num_hits),
+                                       out.ctypes.data, cap, C.byref(n_out))
+            if rc == _lib.ERR_CAPACITY:
+                cap = int(n_out.value)
+                continue
+            check(rc)
+            return out[: n_out.value]
+
+    # ---- device-resident form -------------------------------------------------------------
+    def set_stream(self, hip_stream: int) -> None:
+        check(lib().smafa_db_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_query_block(self, n: int) -> None:
+        check(lib().smafa_set_query_block(self._h, n))
+
+    def scan_launch(self, qset: QuerySet, max_divergence: Optional[int], max_num_hits: Optional[int],
+                    d_hits: int, cap: int, d_count: int) -> None:
+        check(lib().smafa_scan_launch(self._h, qset._h, _opt(max_divergence), _opt(max_num_hits),
+                                      C.c_void_p(d_hits), cap, C.c_void_p(d_count)))
+
+    def sync(self) -> None:
+        check(lib().smafa_sync(self._h))
+
+    def last_scan_ms(self) -> tuple[float, int]:
+        ms, n = C.c_float(0), C.c_uint32(0)
+        check(lib().smafa_last_scan_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self._h:
+            lib().smafa_db_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def select_rows(hits: np.ndarray, n_queries: int, n_subjects: int, subject_codes: Optional[np.ndarray], seq_len: int,
+                max_divergence: Optional[int], max_num_hits: Optional[int],
+                limit_per_sequence: Optional[int]) -> np.ndarray:
+    """Selection rules of src/lib.rs:241-315 over an ordered hit list."""
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    cap = max(len(hits), 1)
+    rows = np.zeros(cap, dtype=HIT_DTYPE)
+    n_rows = C.c_uint64(0)
+    codes_ptr = None
+    if subject_codes is not None:
+        subject_codes = np.ascontiguousarray(subject_codes, dtype=np.uint8)
+        codes_ptr = subject_codes.ctypes.data
+    check(lib().smafa_select_rows(hits.ctypes.data, len(hits), n_queries, n_subjects, codes_ptr, seq_len,
+                                  _opt(max_divergence), _opt(max_num_hits), _opt(limit_per_sequence),
+                                  rows.ctypes.data, cap, C.byref(n_rows)))
+    return rows[: n_rows.value]
+
+
+def read_db(path: str) -> tuple[int, np.ndarray]:
+    """DB file -> (alphabet, code rows)."""
+    alphabet, ptr, n, L = C.c_int(0), C.c_void_p(), C.c_uint64(0), C.c_uint32(0)
+    check(lib().smafa_dbfile_read(os.fsencode(path), C.byref(alphabet), C.byref(ptr), C.byref(n), C.byref(L)))
+    try:
+        size = n.value * L.value
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(max(size, 1),))[:size].copy()
+    finally:
+        lib().smafa_free(ptr)
+    return alphabet.value, arr.reshape(n.value, L.value)
+
+
+def write_db(path: str, codes: np.ndarray, alphabet: int = ALPHABET_NT) -> None:
+    c = np.ascontiguousarray(codes, dtype=np.uint8)
+    check(lib().smafa_dbfile_write(os.fsencode(path), alphabet, c.ctypes.data, c.shape[0], c.shape[1]))
+
+
+# ------------------------------------------------------------------ the crate's pub fns
+def makedb(subject_fasta: str, db_path: str, alphabet: int = ALPHABET_NT) -> None:
+    """makedb(subject_fasta, db_path) — src/lib.rs:137-165."""
+    check(lib().smafa_makedb(os.fsencode(subject_fasta), os.fsencode(db_path), alphabet))
+
+
+def query(db_path: str, query_fasta: str, max_divergence: Optional[int] = None, max_num_hits: Optional[int] = None,
+          limit_per_sequence: Optional[int] = None, out_fd: int = 1, device: int = 0) -> None:
+    """query(db_path, query_fasta, max_divergence, max_num_hits, limit_per_sequence) — src/lib.rs:198-325."""
+    check(lib().smafa_query(os.fsencode(db_path), os.fsencode(query_fasta), _opt(max_divergence), _opt(max_num_hits),
+                            _opt(limit_per_sequence), out_fd, device))
+
+
+def cluster(input_fasta: str, max_divergence: int, out_fd: int = 1, device: int = 0,
+            alphabet: int = ALPHABET_NT) -> None:
+    """cluster(input_fasta, max_divergence, print_stream) — src/cluster.rs:13-94."""
+    check(lib().smafa_cluster(os.fsencode(input_fasta), int(max_divergence), out_fd, device, alphabet))
+
+
+def count(paths, out_fd: int = 1) -> None:
+    """count(paths) — src/lib.rs:378-398."""
+    arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+    check(lib().smafa_count(arr, len(paths), out_fd))

@@ -1,0 +1,31 @@
+// engine.h — internal interfaces shared by the device half (engine.hip) and the host half (host/*.cpp)
+// of libsmafa_amd.so.  No HIP types here: host files are compiled with g++.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/smafa_amd.h"
+
+namespace smafa {
+
+// records the message for smafa_last_error() and returns `code`
+int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Scan `n_queries` code rows against the store; rows ordered by (query, dist, subject); rows above the
+// k-th smallest distance of their query already removed.  max_num_hits: SMAFA_NONE = no k bound.
+int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div, uint32_t max_num_hits,
+                 std::vector<smafa_hit> &out);
+
+// selection rules of src/lib.rs:241-315 (see smafa_select_rows in the public header)
+int select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint64_t n_subjects,
+                const uint8_t *subject_codes, uint32_t seq_len, uint32_t max_div, uint32_t max_num_hits,
+                uint32_t limit_per_sequence, std::vector<smafa_hit> &rows);
+
+// alphabet tables (host/alphabet.cpp)
+uint8_t code_of(int alphabet, uint8_t byte);  // 255 = outside the alphabet
+char letter_of(int alphabet, uint8_t code);
+const char *alphabet_noun(int alphabet);  // "nucleotide" / "amino acid" for the panic text
+
+}  // namespace smafa

@@ -1,0 +1,515 @@
+// engine.hip — device half of the C ABI (include/smafa_amd.h): HBM-resident subject store, packed
+// query sets, scan launches, hit collection.  Host-only entry points (FASTX, DB file, selection,
+// drivers) live in host/*.cpp.  No CPU fallback anywhere: without a HIP device every call here fails.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "engine.h"
+#include "kernels.hip.h"
+
+namespace smafa {
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return set_error(SMAFA_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static int planes_for(int alphabet) { return alphabet == SMAFA_ALPHABET_AA ? 5 : 3; }
+
+}  // namespace smafa
+
+using namespace smafa;
+
+struct smafa_db {
+    int device = 0;
+    int alphabet = 0;
+    uint32_t L = 0, P = 0, W = 0, QS = 0;
+    uint64_t n = 0;          // subjects stored
+    uint64_t cap_tiles = 0;  // allocated wave tiles
+    uint32_t *d_planes = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    uint32_t last_launches = 0;
+    uint32_t qb_override = 0;
+    int n_cu = 256;
+    // scratch of the host-buffer scan API, kept across calls
+    smafa_hit *d_hits = nullptr;
+    uint64_t hits_cap = 0;
+    unsigned long long *d_count = nullptr;
+    size_t tile_words() const { return (size_t)P * W * kWaveTile; }
+};
+
+struct smafa_qset {
+    smafa_db *db = nullptr;
+    uint64_t nq = 0;
+    uint32_t *d_qrec = nullptr;
+    uint32_t *d_thr = nullptr;
+    uint32_t *d_cnt = nullptr;  // lazily allocated: nq * (L+1)
+};
+
+namespace smafa {
+
+static int use_device(const smafa_db *db) {
+    HIP_TRY(hipSetDevice(db->device));
+    return SMAFA_OK;
+}
+
+// upload code rows and pack them with the ballot kernel
+static int pack_rows(smafa_db *db, const uint8_t *codes, uint64_t first, uint64_t n, uint32_t *d_out, int mode) {
+    if (n == 0) return SMAFA_OK;
+    uint8_t *d_codes = nullptr;
+    const size_t bytes = (size_t)n * db->L;
+    HIP_TRY(hipMalloc(&d_codes, bytes));
+    hipError_t e = hipMemcpyAsync(d_codes, codes, bytes, hipMemcpyHostToDevice, db->stream);
+    if (e == hipSuccess) {
+        const uint64_t groups = (first + n + 63) / 64 - first / 64;
+        const uint32_t blocks = (uint32_t)((groups + kWgWaves - 1) / kWgWaves);
+        if (db->P == 5)
+            hipLaunchKernelGGL(pack_rows_kernel<5>, dim3(blocks), dim3(256), 0, db->stream, d_codes, first, n, db->L,
+                               db->W, d_out, mode, db->QS);
+        else
+            hipLaunchKernelGGL(pack_rows_kernel<3>, dim3(blocks), dim3(256), 0, db->stream, d_codes, first, n, db->L,
+                               db->W, d_out, mode, db->QS);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
+    hipFree(d_codes);
+    if (e != hipSuccess) return set_error(SMAFA_ERR_DEVICE, "packing rows failed: %s", hipGetErrorString(e));
+    return SMAFA_OK;
+}
+
+static int validate_codes(const smafa_db *db, const uint8_t *codes, uint64_t n) {
+    const uint8_t lim = db->alphabet == SMAFA_ALPHABET_AA ? 28 : 5;
+    const size_t total = (size_t)n * db->L;
+    uint8_t worst = 0;
+    for (size_t i = 0; i < total; i++) worst = codes[i] > worst ? codes[i] : worst;
+    if (worst >= lim) return set_error(SMAFA_ERR_INVALID, "code byte %u outside the alphabet (max %u)", worst, lim - 1);
+    return SMAFA_OK;
+}
+
+static int reserve_tiles(smafa_db *db, uint64_t need_tiles) {
+    if (need_tiles <= db->cap_tiles) return SMAFA_OK;
+    uint64_t ncap = db->cap_tiles ? db->cap_tiles * 2 : 64;
+    if (ncap < need_tiles) ncap = need_tiles;
+    ncap = (ncap + kWgWaves - 1) / kWgWaves * kWgWaves;
+    uint32_t *d_new = nullptr;
+    const size_t bytes = ncap * db->tile_words() * sizeof(uint32_t);
+    HIP_TRY(hipMalloc(&d_new, bytes));
+    // zero-fill: padding subjects of the last tile read as all-zero planes and are masked by index
+    HIP_TRY(hipMemsetAsync(d_new, 0, bytes, db->stream));
+    if (db->d_planes) {
+        HIP_TRY(hipMemcpyAsync(d_new, db->d_planes, db->cap_tiles * db->tile_words() * sizeof(uint32_t),
+                               hipMemcpyDeviceToDevice, db->stream));
+        HIP_TRY(hipStreamSynchronize(db->stream));
+        HIP_TRY(hipFree(db->d_planes));
+    }
+    db->d_planes = d_new;
+    db->cap_tiles = ncap;
+    return SMAFA_OK;
+}
+
+template <int P, int W>
+static void launch_scan_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
+    hipLaunchKernelGGL((scan_kernel<P, W>), dim3(grid), dim3(256), 0, db->stream,
+                       reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
+}
+
+static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
+#define SMAFA_CASE(P_, W_)                                  \
+    if (db->P == P_ && db->W == W_) {                       \
+        launch_scan_t<P_, W_>(db, d_qrec, a, grid);         \
+        return;                                             \
+    }
+    SMAFA_CASE(3, 1) SMAFA_CASE(3, 2) SMAFA_CASE(3, 3) SMAFA_CASE(3, 4)
+    SMAFA_CASE(5, 1) SMAFA_CASE(5, 2) SMAFA_CASE(5, 3) SMAFA_CASE(5, 4)
+#undef SMAFA_CASE
+    hipLaunchKernelGGL(scan_generic_kernel, dim3(grid), dim3(256), 0, db->stream,
+                       reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a, db->P, db->W, db->QS);
+}
+
+// queries per workgroup pass: big enough that the tile load is amortised (the scan is then bound by
+// VALU issue, not HBM), small enough that the grid has many more workgroups than the chip has slots.
+static uint32_t choose_query_block(const smafa_db *db, uint32_t n_wg_tiles, uint32_t nq) {
+    if (db->qb_override) return std::min<uint32_t>(std::max<uint32_t>(db->qb_override, 1u), std::max(nq, 1u));
+    const uint32_t slots = (uint32_t)db->n_cu * 8u;  // 8 workgroups of 4 waves per CU at <= 64 VGPRs
+    const uint32_t want_items = slots * 16u;
+    uint32_t nqb = (want_items + n_wg_tiles - 1) / n_wg_tiles;
+    const uint32_t max_nqb = std::max(1u, nq / 256u);
+    nqb = std::max(1u, std::min(nqb, max_nqb));
+    uint32_t qb = (nq + nqb - 1) / nqb;
+    return std::max(qb, 1u);
+}
+
+// one kernel launch: queries [q_begin, q_end) x wave tiles [tile_begin, tile_end)
+static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t tile_begin,
+                        uint32_t tile_end, uint32_t k_tight, smafa_hit *d_hits, uint64_t cap,
+                        unsigned long long *d_count) {
+    ScanArgs a;
+    a.tile_begin = tile_begin;
+    a.tile_end = tile_end;
+    a.n_wg_tiles = (tile_end - tile_begin + kWgWaves - 1) / kWgWaves;
+    a.n_subjects = (uint32_t)db->n;
+    a.q_begin = q_begin;
+    a.q_end = q_end;
+    a.qb_size = choose_query_block(db, a.n_wg_tiles, q_end - q_begin);
+    a.thr = qs->d_thr;
+    a.cnt = qs->d_cnt;
+    a.cnt_stride = db->L + 1;
+    a.k_tight = k_tight;
+    a.hits = d_hits;
+    a.cap = cap;
+    a.count = d_count;
+    const uint64_t n_qblocks = (q_end - q_begin + a.qb_size - 1) / a.qb_size;
+    const uint64_t grid = n_qblocks * a.n_wg_tiles;
+    if (grid > 0x7fffffffull)
+        return set_error(SMAFA_ERR_INVALID, "scan grid too large (%llu workgroups)", (unsigned long long)grid);
+    launch_scan(db, qs->d_qrec, a, (uint32_t)grid);
+    HIP_TRY(hipGetLastError());
+    db->last_launches++;
+    return SMAFA_OK;
+}
+
+// Scan queries [q_begin, q_end) of a resident set against the whole store; rows and their count stay on
+// the device.  k_tight = 0: one launch, fixed bound max_div.  k_tight >= 1: the bound of each query is
+// lowered to its running k-th smallest distance while the scan proceeds.  Workgroups of one launch run
+// side by side and would all start from the loose initial bound, so the store is walked in segments that
+// grow 8x per launch (bounds tighten between launches), after a seed launch over the first segment that
+// only lowers the bounds and appends nothing.
+static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t max_div,
+                      uint32_t k_tight, smafa_hit *d_hits, uint64_t cap, unsigned long long *d_count) {
+    const uint32_t nq = q_end - q_begin;
+    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), db->stream));
+    db->last_launches = 0;
+    db->timed = false;
+    if (nq == 0 || db->n == 0) return SMAFA_OK;
+    const uint32_t thr0 = std::min<uint32_t>(max_div, db->L);  // a distance never exceeds seq_len
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream, qs->d_thr + q_begin, thr0,
+                       (uint64_t)nq);
+    const size_t cnt_stride = db->L + 1;
+    auto zero_cnt = [&]() -> int {
+        if (k_tight < 2) return SMAFA_OK;
+        if (!qs->d_cnt) HIP_TRY(hipMalloc(&qs->d_cnt, qs->nq * cnt_stride * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(qs->d_cnt + (size_t)q_begin * cnt_stride, 0, (size_t)nq * cnt_stride * sizeof(uint32_t),
+                               db->stream));
+        return SMAFA_OK;
+    };
+    const uint32_t n_tiles = (uint32_t)((db->n + kWaveTile - 1) / kWaveTile);
+    HIP_TRY(hipEventRecord(db->ev0, db->stream));
+    int rc = SMAFA_OK;
+    if (k_tight == 0) {
+        rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, d_hits, cap, d_count);
+    } else {
+        rc = zero_cnt();
+        const uint32_t seed_tiles = std::min<uint32_t>(kWgWaves, n_tiles);
+        if (!rc) rc = launch_tiles(db, qs, q_begin, q_end, 0, seed_tiles, k_tight, nullptr, 0, d_count);
+        if (!rc) rc = zero_cnt();  // the seed's subjects are counted again below
+        uint32_t begin = 0, len = kWgWaves;
+        while (!rc && begin < n_tiles) {
+            const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)begin + len, n_tiles);
+            rc = launch_tiles(db, qs, q_begin, q_end, begin, end, k_tight, d_hits, cap, d_count);
+            begin = end;
+            len = len > (1u << 28) ? len : len * 8;
+        }
+    }
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(db->ev1, db->stream));
+    db->timed = true;
+    return SMAFA_OK;
+}
+
+static bool hit_less(const smafa_hit &x, const smafa_hit &y) {
+    if (x.query != y.query) return x.query < y.query;
+    if (x.dist != y.dist) return x.dist < y.dist;
+    return x.subject < y.subject;
+}
+
+static int ensure_scratch(smafa_db *db, uint64_t rows) {
+    if (!db->d_count) HIP_TRY(hipMalloc(&db->d_count, sizeof(unsigned long long)));
+    if (rows > db->hits_cap) {
+        if (db->d_hits) HIP_TRY(hipFree(db->d_hits));
+        db->d_hits = nullptr;
+        db->hits_cap = 0;
+        HIP_TRY(hipMalloc(&db->d_hits, rows * sizeof(smafa_hit)));
+        db->hits_cap = rows;
+    }
+    return SMAFA_OK;
+}
+
+// Collect all qualifying rows of queries [q_begin, q_end) into `out` (host, unordered).
+// First try the plain bound when there is one (rows within max_div are usually few); if they do not
+// fit, tighten to the k-th smallest distance; if that still does not fit, halve the query range.
+static int collect_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t max_div,
+                         uint32_t max_num_hits, std::vector<smafa_hit> &out) {
+    const uint32_t k_tight = max_num_hits == SMAFA_NONE ? 0u : max_num_hits;
+    unsigned long long count = 0;
+    bool done = false;
+    for (int attempt = 0; attempt < 2 && !done; attempt++) {
+        uint32_t k;
+        if (attempt == 0) {
+            if (max_div == SMAFA_NONE && k_tight) continue;  // no bound at all: go straight to tightening
+            k = 0;
+        } else {
+            if (!k_tight) break;
+            k = k_tight;
+        }
+        int rc = scan_range(db, qs, q_begin, q_end, max_div, k, db->d_hits, db->hits_cap, db->d_count);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(&count, db->d_count, sizeof count, hipMemcpyDeviceToHost, db->stream));
+        HIP_TRY(hipStreamSynchronize(db->stream));
+        done = count <= db->hits_cap;
+    }
+    if (!done) {
+        if (q_end - q_begin > 1) {
+            const uint32_t mid = q_begin + (q_end - q_begin) / 2;
+            int rc = collect_range(db, qs, q_begin, mid, max_div, max_num_hits, out);
+            if (rc) return rc;
+            return collect_range(db, qs, mid, q_end, max_div, max_num_hits, out);
+        }
+        // one query with more rows than the buffer: it can have at most one row per subject
+        int rc = ensure_scratch(db, std::max<uint64_t>(count, db->n));
+        if (rc) return rc;
+        return collect_range(db, qs, q_begin, q_end, max_div, max_num_hits, out);
+    }
+    const size_t old = out.size();
+    out.resize(old + count);
+    if (count) HIP_TRY(hipMemcpy(out.data() + old, db->d_hits, count * sizeof(smafa_hit), hipMemcpyDeviceToHost));
+    return SMAFA_OK;
+}
+
+int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div,
+                 uint32_t max_num_hits, std::vector<smafa_hit> &out) {
+    out.clear();
+    if (n_queries == 0) return SMAFA_OK;
+    if (n_queries > 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many queries in one batch");
+    int rc = use_device(db);
+    if (rc) return rc;
+    rc = ensure_scratch(db, 1ull << 22);  // 4M rows = 48 MiB to start with
+    if (rc) return rc;
+    smafa_qset *qs = nullptr;
+    rc = smafa_qset_create(&qs, db, query_codes, n_queries);
+    if (rc) return rc;
+    rc = collect_range(db, qs, 0, (uint32_t)n_queries, max_div, max_num_hits, out);
+    smafa_qset_destroy(qs);
+    if (rc) return rc;
+    std::sort(out.begin(), out.end(), hit_less);
+    if (max_num_hits != SMAFA_NONE && max_num_hits >= 1) {
+        // drop rows above the k-th smallest distance of their query (the device bound only tightens)
+        size_t w = 0, i = 0;
+        while (i < out.size()) {
+            size_t j = i;
+            while (j < out.size() && out[j].query == out[i].query) j++;
+            const size_t cnt = j - i;
+            const uint32_t kth = cnt >= max_num_hits ? out[i + max_num_hits - 1].dist : UINT32_MAX;
+            for (size_t t = i; t < j && out[t].dist <= kth; t++) out[w++] = out[t];
+            i = j;
+        }
+        out.resize(w);
+    }
+    return SMAFA_OK;
+}
+
+}  // namespace smafa
+
+// ------------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+int smafa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) {
+    if (!out) return set_error(SMAFA_ERR_INVALID, "smafa_db_create: out is NULL");
+    *out = nullptr;
+    if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
+        return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
+    if (seq_len == 0) return set_error(SMAFA_ERR_PANIC, "Cannot add empty sequence to WindowSet");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return set_error(SMAFA_ERR_DEVICE, "no HIP device visible: the smafa scan engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return set_error(SMAFA_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    smafa_db *db = new smafa_db();
+    db->device = device;
+    db->alphabet = alphabet;
+    db->L = seq_len;
+    db->P = (uint32_t)planes_for(alphabet);
+    db->W = (seq_len + 31) / 32;
+    db->QS = (uint32_t)round_up4((int)(db->P * db->W));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) db->n_cu = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&db->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&db->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&db->ev1);
+    if (e != hipSuccess) {
+        smafa_db_destroy(db);
+        return set_error(SMAFA_ERR_DEVICE, "stream/event creation failed: %s", hipGetErrorString(e));
+    }
+    db->stream = db->own_stream;
+    *out = db;
+    return SMAFA_OK;
+}
+
+int smafa_db_append(smafa_db *db, const uint8_t *codes, uint64_t n) {
+    if (!db || (!codes && n)) return set_error(SMAFA_ERR_INVALID, "smafa_db_append: NULL argument");
+    if (n == 0) return SMAFA_OK;
+    if (db->n + n > 0xffffff00ull) return set_error(SMAFA_ERR_INVALID, "subject store limited to 2^32 rows");
+    int rc = use_device(db);
+    if (rc) return rc;
+    rc = validate_codes(db, codes, n);
+    if (rc) return rc;
+    rc = reserve_tiles(db, (db->n + n + kWaveTile - 1) / kWaveTile);
+    if (rc) return rc;
+    rc = pack_rows(db, codes, db->n, n, db->d_planes, 0);
+    if (rc) return rc;
+    db->n += n;
+    return SMAFA_OK;
+}
+
+int smafa_db_info(const smafa_db *db, smafa_db_info_t *info) {
+    if (!db || !info) return set_error(SMAFA_ERR_INVALID, "smafa_db_info: NULL argument");
+    info->n_subjects = db->n;
+    info->seq_len = db->L;
+    info->alphabet = db->alphabet;
+    info->device = db->device;
+    info->planes = db->P;
+    info->words_per_plane = db->W;
+    info->bytes_per_subject = (uint64_t)db->P * db->W * 4;
+    info->hbm_bytes = (db->n + kWaveTile - 1) / kWaveTile * db->tile_words() * sizeof(uint32_t);
+    return SMAFA_OK;
+}
+
+int smafa_db_set_stream(smafa_db *db, void *hip_stream) {
+    if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_db_set_stream: NULL handle");
+    db->stream = hip_stream ? (hipStream_t)hip_stream : db->own_stream;
+    return SMAFA_OK;
+}
+
+void smafa_db_destroy(smafa_db *db) {
+    if (!db) return;
+    hipSetDevice(db->device);
+    if (db->d_planes) hipFree(db->d_planes);
+    if (db->d_hits) hipFree(db->d_hits);
+    if (db->d_count) hipFree(db->d_count);
+    if (db->ev0) hipEventDestroy(db->ev0);
+    if (db->ev1) hipEventDestroy(db->ev1);
+    if (db->own_stream) hipStreamDestroy(db->own_stream);
+    delete db;
+}
+
+int smafa_set_query_block(smafa_db *db, uint32_t queries_per_block) {
+    if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_set_query_block: NULL handle");
+    db->qb_override = queries_per_block;
+    return SMAFA_OK;
+}
+
+int smafa_qset_create(smafa_qset **out, smafa_db *db, const uint8_t *query_codes, uint64_t n_queries) {
+    if (!out || !db || (!query_codes && n_queries)) return set_error(SMAFA_ERR_INVALID, "smafa_qset_create: NULL argument");
+    *out = nullptr;
+    if (n_queries > 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many queries in one set");
+    int rc = use_device(db);
+    if (rc) return rc;
+    rc = validate_codes(db, query_codes, n_queries);
+    if (rc) return rc;
+    smafa_qset *qs = new smafa_qset();
+    qs->db = db;
+    qs->nq = n_queries;
+    const uint64_t padded = (n_queries + 63) / 64 * 64;
+    hipError_t e = hipMalloc(&qs->d_qrec, std::max<uint64_t>(padded, 64) * db->QS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&qs->d_thr, std::max<uint64_t>(padded, 64) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(qs->d_qrec, 0, std::max<uint64_t>(padded, 64) * db->QS * sizeof(uint32_t), db->stream);
+    if (e != hipSuccess) {
+        smafa_qset_destroy(qs);
+        return set_error(SMAFA_ERR_DEVICE, "query set allocation failed: %s", hipGetErrorString(e));
+    }
+    rc = pack_rows(db, query_codes, 0, n_queries, qs->d_qrec, 1);
+    if (rc) {
+        smafa_qset_destroy(qs);
+        return rc;
+    }
+    *out = qs;
+    return SMAFA_OK;
+}
+
+void smafa_qset_destroy(smafa_qset *qs) {
+    if (!qs) return;
+    if (qs->db) hipSetDevice(qs->db->device);
+    if (qs->d_qrec) hipFree(qs->d_qrec);
+    if (qs->d_thr) hipFree(qs->d_thr);
+    if (qs->d_cnt) hipFree(qs->d_cnt);
+    delete qs;
+}
+
+int smafa_scan_launch(smafa_db *db, smafa_qset *qs, uint32_t max_div, uint32_t max_num_hits, void *d_hits,
+                      uint64_t cap, void *d_count) {
+    if (!db || !qs || !d_count || (!d_hits && cap)) return set_error(SMAFA_ERR_INVALID, "smafa_scan_launch: NULL argument");
+    if (qs->db != db) return set_error(SMAFA_ERR_INVALID, "query set was packed for a different store");
+    if (max_num_hits == 0) max_num_hits = SMAFA_NONE;
+    int rc = use_device(db);
+    if (rc) return rc;
+    return scan_range(db, qs, 0, (uint32_t)qs->nq, max_div, max_num_hits == SMAFA_NONE ? 0u : max_num_hits,
+                      (smafa_hit *)d_hits, cap, (unsigned long long *)d_count);
+}
+
+int smafa_sync(smafa_db *db) {
+    if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_sync: NULL handle");
+    HIP_TRY(hipStreamSynchronize(db->stream));
+    return SMAFA_OK;
+}
+
+int smafa_last_scan_ms(smafa_db *db, float *ms, uint32_t *n_launches) {
+    if (!db || !ms) return set_error(SMAFA_ERR_INVALID, "smafa_last_scan_ms: NULL argument");
+    *ms = 0.f;
+    if (n_launches) *n_launches = db->last_launches;
+    if (!db->timed) return SMAFA_OK;
+    HIP_TRY(hipEventSynchronize(db->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, db->ev0, db->ev1));
+    return SMAFA_OK;
+}
+
+int smafa_scan_hits(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div,
+                    uint32_t max_num_hits, smafa_hit *out, uint64_t cap, uint64_t *n_out) {
+    if (!db || !n_out || (!query_codes && n_queries) || (!out && cap))
+        return set_error(SMAFA_ERR_INVALID, "smafa_scan_hits: NULL argument");
+    if (max_num_hits == 0) max_num_hits = SMAFA_NONE;
+    std::vector<smafa_hit> rows;
+    int rc = scan_to_host(db, query_codes, n_queries, max_div, max_num_hits, rows);
+    if (rc) return rc;
+    *n_out = rows.size();
+    if (rows.size() > cap)
+        return set_error(SMAFA_ERR_CAPACITY, "hit buffer too small: %zu rows needed, capacity %llu", rows.size(),
+                         (unsigned long long)cap);
+    if (!rows.empty()) memcpy(out, rows.data(), rows.size() * sizeof(smafa_hit));
+    return SMAFA_OK;
+}
+
+int smafa_distances(smafa_db *db, const uint8_t *query_codes, uint32_t *distances) {
+    if (!db || !query_codes || (!distances && db->n)) return set_error(SMAFA_ERR_INVALID, "smafa_distances: NULL argument");
+    if (db->n == 0) return SMAFA_OK;
+    int rc = use_device(db);
+    if (rc) return rc;
+    smafa_qset *qs = nullptr;
+    rc = smafa_qset_create(&qs, db, query_codes, 1);
+    if (rc) return rc;
+    const uint32_t n_tiles = (uint32_t)((db->n + kWaveTile - 1) / kWaveTile);
+    uint4 *d_out = nullptr;
+    hipError_t e = hipMalloc(&d_out, (size_t)n_tiles * kWaveTile * sizeof(uint32_t));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(distances_kernel, dim3((n_tiles + kWgWaves - 1) / kWgWaves), dim3(256), 0, db->stream,
+                           reinterpret_cast<const uint4 *>(db->d_planes), n_tiles, db->P, db->W, qs->d_qrec, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(distances, d_out, db->n * sizeof(uint32_t), hipMemcpyDeviceToHost, db->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
+    hipFree(d_out);
+    smafa_qset_destroy(qs);
+    if (e != hipSuccess) return set_error(SMAFA_ERR_DEVICE, "distances kernel failed: %s", hipGetErrorString(e));
+    return SMAFA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,477 @@
+// drivers.cpp — the reference crate's public functions over the HIP scan engine:
+//   makedb  (/root/reference/src/lib.rs:137-165)   host only
+//   query   (/root/reference/src/lib.rs:198-325)   scan on the GPU, selection + TSV on the host
+//   cluster (/root/reference/src/cluster.rs:13-94) batched, exact restatement of the greedy loop
+//   count   (/root/reference/src/lib.rs:378-398)   host only
+// Output bytes are the reference's: `query` prints "{query}\t{subject}\t{distance}\t{subject string}\n"
+// (src/lib.rs:292,310), `cluster` prints "{raw record}\t{centroid string}\n" (src/cluster.rs:79-84).
+// Inputs the reference panics on fail with SMAFA_ERR_PANIC and the same message, after the rows the
+// reference would already have printed.
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../engine.h"
+#include "fastx.h"
+
+namespace smafa {
+
+namespace {
+
+int write_all(int fd, const char *p, size_t n) {
+    while (n) {
+        const ssize_t w = ::write(fd, p, n);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            return set_error(SMAFA_ERR_IO, "write failed: %s", strerror(errno));
+        }
+        p += w;
+        n -= (size_t)w;
+    }
+    return SMAFA_OK;
+}
+
+// encode one record; on a byte outside the alphabet produce the panic text of src/lib.rs:38-41
+int encode_record(int alphabet, const FastxRecord &rec, std::vector<uint8_t> &codes) {
+    const size_t base = codes.size();
+    codes.resize(base + rec.seq_len);
+    for (size_t i = 0; i < rec.seq_len; i++) {
+        const uint8_t c = code_of(alphabet, rec.seq[i]);
+        if (c == 255) {
+            codes.resize(base);
+            return set_error(SMAFA_ERR_PANIC, "Byte %u cannot be interpreted as %s, in sequence \"%.*s\" at position %zu",
+                             rec.seq[i], alphabet_noun(alphabet), (int)rec.id_len, (const char *)rec.id, i);
+        }
+        codes[base + i] = c;
+    }
+    return SMAFA_OK;
+}
+
+void append_u32(std::string &s, uint32_t v) {
+    char tmp[12];
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) s.push_back(tmp[--n]);
+}
+
+void append_decoded(std::string &s, int alphabet, const uint8_t *codes, uint32_t L) {
+    const size_t base = s.size();
+    s.resize(base + L);
+    for (uint32_t i = 0; i < L; i++) s[base + i] = letter_of(alphabet, codes[i]);
+}
+
+struct DbGuard {
+    smafa_db *db = nullptr;
+    ~DbGuard() { smafa_db_destroy(db); }
+};
+
+struct FreeGuard {
+    void *p = nullptr;
+    ~FreeGuard() { smafa_free(p); }
+};
+
+// fixed-width row set with open addressing: HashSet<Vec<u64>> of src/cluster.rs:24
+class RowSet {
+  public:
+    RowSet(const uint8_t *rows, uint32_t L) : rows_(rows), L_(L), slots_(1024, UINT32_MAX) {}
+    void rebase(const uint8_t *rows) { rows_ = rows; }
+    // true if row `idx` was not present before
+    bool insert(uint32_t idx) {
+        if ((count_ + 1) * 2 > slots_.size()) grow();
+        return put(idx);
+    }
+
+  private:
+    uint64_t hash(const uint8_t *p) const {
+        uint64_t h = 0x9e3779b97f4a7c15ull;
+        uint32_t i = 0;
+        for (; i + 8 <= L_; i += 8) {
+            uint64_t v;
+            memcpy(&v, p + i, 8);
+            h = (h ^ v) * 0xff51afd7ed558ccdull;
+            h ^= h >> 32;
+        }
+        for (; i < L_; i++) h = (h ^ p[i]) * 0x100000001b3ull;
+        return h ^ (h >> 29);
+    }
+    bool put(uint32_t idx) {
+        const uint8_t *row = rows_ + (size_t)idx * L_;
+        size_t s = hash(row) & (slots_.size() - 1);
+        while (slots_[s] != UINT32_MAX) {
+            if (memcmp(rows_ + (size_t)slots_[s] * L_, row, L_) == 0) return false;
+            s = (s + 1) & (slots_.size() - 1);
+        }
+        slots_[s] = idx;
+        count_++;
+        return true;
+    }
+    void grow() {
+        std::vector<uint32_t> old;
+        old.swap(slots_);
+        slots_.assign(old.size() * 2, UINT32_MAX);
+        count_ = 0;
+        for (uint32_t v : old)
+            if (v != UINT32_MAX) put(v);
+    }
+    const uint8_t *rows_;
+    uint32_t L_;
+    std::vector<uint32_t> slots_;
+    size_t count_ = 0;
+};
+
+}  // namespace
+
+}  // namespace smafa
+
+using namespace smafa;
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------- makedb
+int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet) {
+    if (!subject_fasta || !db_path) return set_error(SMAFA_ERR_INVALID, "smafa_makedb: NULL path");
+    if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
+        return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
+    FastxReader reader;
+    int rc = reader.open(subject_fasta);  // src/lib.rs:143-144
+    if (rc) return rc;
+    std::vector<uint8_t> codes;
+    uint64_t n = 0;
+    size_t L = 0;
+    FastxRecord rec;
+    while ((rc = reader.next(rec)) == 1) {
+        if (n == 0) {
+            if (rec.seq_len == 0)  // src/lib.rs:103-108
+                return set_error(SMAFA_ERR_PANIC, "Cannot add empty sequence to WindowSet");
+            L = rec.seq_len;
+        }
+        int erc = encode_record(alphabet, rec, codes);  // src/lib.rs:150 — encoding comes before the length check
+        if (erc) return erc;
+        if (rec.seq_len != L)  // src/lib.rs:92-101
+            return set_error(SMAFA_ERR_PANIC, "WindowSet seq length is %zu, got a new sequence of length %zu", L, rec.seq_len);
+        n++;
+    }
+    if (rc < 0) return rc;
+    if (L > 0xffffffffull) return set_error(SMAFA_ERR_INVALID, "sequence too long");
+    return smafa_dbfile_write(db_path, alphabet, codes.data(), n, (uint32_t)L);  // src/lib.rs:161-162
+}
+
+// -------------------------------------------------------------------------------------- query
+int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_divergence, uint32_t max_num_hits,
+                uint32_t limit_per_sequence, int out_fd, int device) {
+    if (!db_path || !query_fasta) return set_error(SMAFA_ERR_INVALID, "smafa_query: NULL path");
+    int alphabet = 0;
+    uint64_t n = 0;
+    uint32_t L = 0;
+    FreeGuard codes_guard;
+    uint8_t *codes = nullptr;
+    int rc = smafa_dbfile_read(db_path, &alphabet, &codes, &n, &L);  // src/lib.rs:208-218
+    if (rc) return rc;
+    codes_guard.p = codes;
+
+    FastxReader reader;
+    rc = reader.open(query_fasta);  // src/lib.rs:221
+    if (rc) return rc;
+
+    DbGuard guard;
+    if (n > 0) {
+        rc = smafa_db_create(&guard.db, device, alphabet, L);
+        if (rc) return rc;
+        rc = smafa_db_append(guard.db, codes, n);
+        if (rc) return rc;
+    }
+
+    const bool kmode = max_num_hits != SMAFA_NONE && max_num_hits != 1;  // src/lib.rs:224
+    // the device bound: k-th smallest distance (k = 1: the minimum); no k bound when k exceeds the store
+    const uint32_t dev_k = !kmode ? 1u : (max_num_hits == 0 || max_num_hits > (uint32_t)n) ? SMAFA_NONE : max_num_hits;
+    // rows per query are bounded by the store size when nothing else bounds them
+    const bool unbounded = max_divergence == SMAFA_NONE && dev_k == SMAFA_NONE;
+    const uint64_t chunk_queries = unbounded ? std::max<uint64_t>(1, (16ull << 20) / std::max<uint64_t>(n, 1)) : 65536;
+
+    std::vector<uint8_t> qcodes;
+    std::vector<smafa_hit> hits, rows;
+    std::string text;
+    uint32_t query_number = 0;  // src/lib.rs:231
+    uint64_t in_chunk = 0;
+    int pending = SMAFA_OK;  // error to report after the rows already due have been printed
+    std::string pending_msg;
+
+    auto flush = [&]() -> int {
+        if (in_chunk == 0) return SMAFA_OK;
+        hits.clear();
+        if (n > 0) {
+            int r = scan_to_host(guard.db, qcodes.data(), in_chunk, max_divergence, dev_k, hits);
+            if (r) return r;
+        }
+        int r = select_rows(hits.data(), hits.size(), in_chunk, n, codes, L, max_divergence, max_num_hits,
+                            limit_per_sequence, rows);
+        if (r) return r;
+        text.clear();
+        const uint32_t q_base = query_number - (uint32_t)in_chunk;
+        for (const smafa_hit &h : rows) {
+            append_u32(text, q_base + h.query);
+            text.push_back('\t');
+            append_u32(text, h.subject);
+            text.push_back('\t');
+            append_u32(text, h.dist);
+            text.push_back('\t');
+            append_decoded(text, alphabet, codes + (size_t)h.subject * L, L);
+            text.push_back('\n');
+        }
+        in_chunk = 0;
+        qcodes.clear();
+        return write_all(out_fd, text.data(), text.size());
+    };
+
+    FastxRecord rec;
+    while ((rc = reader.next(rec)) == 1) {
+        int erc = encode_record(alphabet, rec, qcodes);  // src/lib.rs:235
+        if (erc) {
+            pending = erc;
+            pending_msg = smafa_last_error();
+            break;
+        }
+        if (n > 0 && rec.seq_len != L) {  // src/lib.rs:72-79 (only checked when the store has a length)
+            qcodes.resize(qcodes.size() - rec.seq_len);
+            pending = SMAFA_ERR_PANIC;
+            char msg[160];
+            snprintf(msg, sizeof msg, "Cannot compute distances between seq of length %zu and windows of lengths %u",
+                     rec.seq_len, L);
+            pending_msg = msg;
+            break;
+        }
+        if (n == 0) qcodes.resize(qcodes.size() - rec.seq_len);  // nothing to compare with; selection will panic
+        in_chunk++;
+        query_number++;
+        if (in_chunk >= chunk_queries) {
+            int frc = flush();
+            if (frc) return frc;
+        }
+    }
+    if (rc < 0 && pending == SMAFA_OK) {
+        pending = rc;
+        pending_msg = smafa_last_error();
+    }
+    int frc = flush();
+    if (frc) return frc;
+    if (pending != SMAFA_OK) return set_error(pending, "%s", pending_msg.c_str());
+    return SMAFA_OK;
+}
+
+// ------------------------------------------------------------------------------------ cluster
+//
+// The reference handles one record at a time: skip exact duplicates, scan the record against the
+// centroids found so far, join the nearest one if it is within max_divergence (ties: lowest centroid
+// index), else become a new centroid (src/cluster.rs:35-85).  The same assignment is computed here in
+// batches of B unseen records:
+//   1. one GPU scan of the batch against the centroids known BEFORE the batch (bound: max_divergence,
+//      tightened to each record's minimum) -> per record its nearest old centroid, lowest index on ties;
+//   2. records with no old centroid in range are the only ones that can become centroids in this batch
+//      ("candidates"); one GPU scan of the batch against the candidates gives every in-range
+//      (record, candidate) pair;
+//   3. a sequential pass in input order decides, for each record, between its old centroid and the
+//      candidates EARLIER in the batch that did become centroids — old centroids have smaller indices
+//      than new ones, and new ones are numbered in input order, so "smallest distance, then lowest
+//      centroid index" is evaluated exactly as the reference's first-minimum scan (src/cluster.rs:62-68).
+// Nothing is approximated: the result is the reference's, record for record.
+int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet) {
+    if (!input_fasta) return set_error(SMAFA_ERR_INVALID, "smafa_cluster: NULL path");
+    if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
+        return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
+    FastxReader reader;
+    int rc = reader.open(input_fasta);  // src/cluster.rs:28
+    if (rc) return rc;
+
+    std::vector<uint8_t> raw, codes;
+    uint64_t n = 0;
+    size_t L = 0;
+    int pending = SMAFA_OK;
+    std::string pending_msg;
+    FastxRecord rec;
+    while ((rc = reader.next(rec)) == 1) {
+        int erc = encode_record(alphabet, rec, codes);  // src/cluster.rs:42-43
+        if (erc) {
+            pending = erc;
+            pending_msg = smafa_last_error();
+            break;
+        }
+        if (n == 0) {
+            if (rec.seq_len == 0) {  // first record becomes a centroid: push_encoding, src/lib.rs:103-108
+                pending = SMAFA_ERR_PANIC;
+                pending_msg = "Cannot add empty sequence to WindowSet";
+                break;
+            }
+            L = rec.seq_len;
+        } else if (rec.seq_len != L) {  // get_distances, src/lib.rs:72-79
+            codes.resize(codes.size() - rec.seq_len);
+            pending = SMAFA_ERR_PANIC;
+            char msg[160];
+            snprintf(msg, sizeof msg, "Cannot compute distances between seq of length %zu and windows of lengths %zu",
+                     rec.seq_len, L);
+            pending_msg = msg;
+            break;
+        }
+        raw.insert(raw.end(), rec.seq, rec.seq + rec.seq_len);
+        n++;
+        if (n >= 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many records");
+    }
+    if (rc < 0 && pending == SMAFA_OK) {
+        pending = rc;
+        pending_msg = smafa_last_error();
+    }
+
+    if (n > 0) {
+        const uint32_t Lw = (uint32_t)L;
+        // exact-duplicate skip (src/cluster.rs:46-48): first occurrences only, input order
+        std::vector<uint32_t> uniq;
+        uniq.reserve(n);
+        {
+            RowSet seen(codes.data(), Lw);
+            for (uint64_t i = 0; i < n; i++)
+                if (seen.insert((uint32_t)i)) uniq.push_back((uint32_t)i);
+        }
+        std::vector<uint32_t> centroid_of(n, UINT32_MAX);  // record -> centroid ordinal
+        std::vector<uint32_t> centroid_rec;                // centroid ordinal -> record
+
+        DbGuard centroids;
+        rc = smafa_db_create(&centroids.db, device, alphabet, Lw);
+        if (rc) return rc;
+
+        std::vector<uint8_t> batch_codes, cand_codes, new_codes;
+        std::vector<smafa_hit> old_hits, cand_hits;
+        std::vector<uint32_t> cand_pos;        // candidate ordinal -> position in the batch
+        std::vector<uint32_t> cand_centroid;   // candidate ordinal -> centroid ordinal it became (or NONE)
+        size_t pos = 0, B = 1024;
+        while (pos < uniq.size()) {
+            const size_t nb = std::min(B, uniq.size() - pos);
+            batch_codes.resize(nb * L);
+            for (size_t b = 0; b < nb; b++) memcpy(&batch_codes[b * L], &codes[(size_t)uniq[pos + b] * L], L);
+
+            // 1. nearest old centroid per record: rows ordered (record, distance, centroid), minimum only
+            old_hits.clear();
+            if (!centroid_rec.empty()) {
+                rc = scan_to_host(centroids.db, batch_codes.data(), nb, max_divergence, 1, old_hits);
+                if (rc) return rc;
+            }
+            std::vector<uint32_t> old_d(nb, UINT32_MAX), old_c(nb, UINT32_MAX);
+            for (size_t t = old_hits.size(); t-- > 0;) {  // backwards: the first row of each record wins
+                old_d[old_hits[t].query] = old_hits[t].dist;
+                old_c[old_hits[t].query] = old_hits[t].subject;
+            }
+
+            // 2. candidates = records with no old centroid in range
+            cand_pos.clear();
+            cand_codes.clear();
+            for (size_t b = 0; b < nb; b++)
+                if (old_c[b] == UINT32_MAX) {
+                    cand_pos.push_back((uint32_t)b);
+                    cand_codes.insert(cand_codes.end(), &batch_codes[b * L], &batch_codes[b * L] + L);
+                }
+            cand_hits.clear();
+            if (!cand_pos.empty()) {
+                DbGuard cand;
+                rc = smafa_db_create(&cand.db, device, alphabet, Lw);
+                if (rc) return rc;
+                rc = smafa_db_append(cand.db, cand_codes.data(), cand_pos.size());
+                if (rc) return rc;
+                rc = scan_to_host(cand.db, batch_codes.data(), nb, max_divergence, SMAFA_NONE, cand_hits);
+                if (rc) return rc;
+            }
+
+            // 3. sequential pass in input order
+            cand_centroid.assign(cand_pos.size(), UINT32_MAX);
+            new_codes.clear();
+            size_t h = 0, next_cand = 0;
+            for (size_t b = 0; b < nb; b++) {
+                uint32_t best_d = old_d[b], best_c = old_c[b];
+                // rows of this record are ordered (distance, candidate); candidates that became centroids
+                // are numbered in batch order, so the first admissible row is the best new centroid
+                while (h < cand_hits.size() && cand_hits[h].query < b) h++;
+                for (size_t t = h; t < cand_hits.size() && cand_hits[t].query == b; t++) {
+                    const uint32_t c = cand_hits[t].subject;
+                    if (cand_pos[c] >= b || cand_centroid[c] == UINT32_MAX) continue;  // later record / not a centroid
+                    if (cand_hits[t].dist < best_d) {  // strict: an old centroid wins ties (lower index)
+                        best_d = cand_hits[t].dist;
+                        best_c = cand_centroid[c];
+                    }
+                    break;
+                }
+                const uint32_t record = uniq[pos + b];
+                if (best_c != UINT32_MAX && best_d <= max_divergence) {  // src/cluster.rs:62-68
+                    centroid_of[record] = best_c;
+                } else {  // src/cluster.rs:69-74
+                    while (cand_pos[next_cand] != b) next_cand++;
+                    cand_centroid[next_cand] = (uint32_t)centroid_rec.size();
+                    centroid_of[record] = (uint32_t)centroid_rec.size();
+                    centroid_rec.push_back(record);
+                    new_codes.insert(new_codes.end(), &batch_codes[b * L], &batch_codes[b * L] + L);
+                }
+            }
+            if (!new_codes.empty()) {
+                rc = smafa_db_append(centroids.db, new_codes.data(), new_codes.size() / L);
+                if (rc) return rc;
+            }
+            pos += nb;
+            // batch size follows the row volume: grow while the scans stay cheap, shrink on dense input
+            const size_t volume = old_hits.size() + cand_hits.size();
+            if (volume < (4u << 20) && B < 65536) B *= 2;
+            else if (volume > (16u << 20) && B > 256) B /= 2;
+        }
+
+        // src/cluster.rs:79-84
+        std::string text;
+        text.reserve(1 << 20);
+        for (uint64_t i = 0; i < n; i++) {
+            if (centroid_of[i] == UINT32_MAX) continue;  // duplicate: no line
+            text.append((const char *)&raw[i * L], L);
+            text.push_back('\t');
+            append_decoded(text, alphabet, &codes[(size_t)centroid_rec[centroid_of[i]] * L], Lw);
+            text.push_back('\n');
+            if (text.size() > (1u << 20)) {
+                rc = write_all(out_fd, text.data(), text.size());
+                if (rc) return rc;
+                text.clear();
+            }
+        }
+        rc = write_all(out_fd, text.data(), text.size());
+        if (rc) return rc;
+    }
+    if (pending != SMAFA_OK) return set_error(pending, "%s", pending_msg.c_str());
+    return SMAFA_OK;
+}
+
+// -------------------------------------------------------------------------------------- count
+int smafa_count(const char *const *paths, uint64_t n_paths, int out_fd) {
+    std::string text = "[";
+    for (uint64_t i = 0; i < n_paths; i++) {
+        FastxReader reader;
+        int rc = reader.open(paths[i]);
+        if (rc) return rc;
+        uint64_t reads = 0, bases = 0;
+        FastxRecord rec;
+        while ((rc = reader.next(rec)) == 1) {
+            reads++;
+            bases += rec.seq_len;
+        }
+        if (rc < 0) return rc;
+        if (i) text.push_back(',');
+        text += "{\"path\":\"";
+        for (const char *c = paths[i]; *c; c++) {
+            if (*c == '"' || *c == '\\') text.push_back('\\');
+            text.push_back(*c);
+        }
+        text += "\",\"num_reads\":" + std::to_string(reads) + ",\"num_bases\":" + std::to_string(bases) + "}";
+    }
+    text += "]\n";
+    return write_all(out_fd, text.data(), text.size());
+}
+
+}  // extern "C"

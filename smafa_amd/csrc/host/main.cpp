@@ -1,0 +1,123 @@
+// main.cpp — the `smafa` command line over libsmafa_amd.so.  Subcommands, flag names and value types
+// follow the reference's clap tree (/root/reference/src/main.rs:64-116):
+//   makedb  -i/--input FILE  -d/--database FILE
+//   query   -d/--database FILE  -q/--query FILE  [--max-divergence INT] [--max-num-hits INT]
+//           [--limit-per-sequence INT]
+//   cluster -i/--input FILE  -d/--max-divergence INT
+//   count   -i/--input FILE...
+// plus -v/--verbose and --quiet (logging only; results are the only thing on stdout).
+// Additions of this build: --device N (query, cluster), --alphabet nt|aa (makedb, cluster).
+// Exit status: 0 ok, 101 where the reference panics (a Rust panic exits 101), 1 other failures, 2 usage.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/smafa_amd.h"
+
+static int usage(const char *msg) {
+    if (msg) fprintf(stderr, "error: %s\n\n", msg);
+    fprintf(stderr,
+            "Usage: smafa <COMMAND>\n\n"
+            "Commands:\n"
+            "  makedb   Generate a searchable database\n"
+            "  query    Search a database. See query --help for more information about output format.\n"
+            "  cluster  Cluster sequences by similarity\n"
+            "  count    Print the number of reads/bases in a possibly gzipped FASTX file\n\n"
+            "makedb  -i, --input <FILE>  -d, --database <FILE>  [--alphabet nt|aa]\n"
+            "query   -d, --database <FILE>  -q, --query <FILE>  [--max-divergence <INT>] [--max-num-hits <INT>]\n"
+            "        [--limit-per-sequence <INT>] [--device <N>]\n"
+            "        Output columns (tab-separated): query number (0-indexed), subject number (0-indexed),\n"
+            "        divergence, subject sequence (dashes and degenerate bases shown as N)\n"
+            "cluster -i, --input <FILE>  -d, --max-divergence <INT>  [--alphabet nt|aa] [--device <N>]\n"
+            "count   -i, --input <FILE>...\n");
+    return 2;
+}
+
+static bool parse_u32(const char *s, uint32_t *out) {
+    if (!s || !*s || *s == '-' || *s == '+') return false;
+    char *end = nullptr;
+    const unsigned long long v = strtoull(s, &end, 10);
+    if (*end || v > 0xffffffffull) return false;
+    *out = (uint32_t)v;
+    return true;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) return usage(nullptr);
+    const std::string cmd = argv[1];
+    if (cmd == "-h" || cmd == "--help") {
+        usage(nullptr);
+        return 0;
+    }
+    const bool is_cluster = cmd == "cluster";
+    const char *input = nullptr, *database = nullptr, *query = nullptr;
+    std::vector<const char *> count_paths;
+    uint32_t max_div = SMAFA_NONE, max_hits = SMAFA_NONE, limit = SMAFA_NONE, device = 0;
+    bool have_max_div = false;
+    int alphabet = SMAFA_ALPHABET_NT;
+    for (int i = 2; i < argc; i++) {
+        const std::string a = argv[i];
+        auto value = [&]() -> const char * { return i + 1 < argc ? argv[++i] : nullptr; };
+        if (a == "-i" || a == "--input") {
+            if (cmd == "count") {
+                while (i + 1 < argc && argv[i + 1][0] != '-') count_paths.push_back(argv[++i]);
+            } else if (!(input = value())) {
+                return usage("--input needs a value");
+            }
+        } else if (a == "--database" || (a == "-d" && !is_cluster)) {
+            if (!(database = value())) return usage("--database needs a value");
+        } else if (a == "--max-divergence" || (a == "-d" && is_cluster)) {
+            if (!parse_u32(value(), &max_div)) return usage("--max-divergence needs an unsigned integer");
+            have_max_div = true;
+        } else if (a == "-q" || a == "--query") {
+            if (cmd == "query") {
+                if (!(query = value())) return usage("--query needs a value");
+            }  // elsewhere -q is --quiet
+        } else if (a == "--max-num-hits") {
+            if (!parse_u32(value(), &max_hits)) return usage("--max-num-hits needs an unsigned integer");
+        } else if (a == "--limit-per-sequence") {
+            if (!parse_u32(value(), &limit)) return usage("--limit-per-sequence needs an unsigned integer");
+        } else if (a == "--device") {
+            if (!parse_u32(value(), &device)) return usage("--device needs an unsigned integer");
+        } else if (a == "--alphabet") {
+            const char *v = value();
+            if (v && !strcmp(v, "nt")) alphabet = SMAFA_ALPHABET_NT;
+            else if (v && !strcmp(v, "aa")) alphabet = SMAFA_ALPHABET_AA;
+            else return usage("--alphabet is nt or aa");
+        } else if (a == "-v" || a == "--verbose" || a == "--quiet") {
+            // logging flags of bird_tool_utils: stderr only, nothing to change here
+        } else if (a == "-h" || a == "--help") {
+            usage(nullptr);
+            return 0;
+        } else {
+            return usage(("unexpected argument " + a).c_str());
+        }
+    }
+    int rc;
+    if (cmd == "makedb") {
+        if (!input || !database) return usage("makedb needs --input and --database");
+        rc = smafa_makedb(input, database, alphabet);
+    } else if (cmd == "query") {
+        if (!database || !query) return usage("query needs --database and --query");
+        rc = smafa_query(database, query, max_div, max_hits, limit, 1, (int)device);
+    } else if (is_cluster) {
+        if (!input) return usage("cluster needs --input");
+        if (!have_max_div) {  // src/main.rs:43 unwraps the option
+            fprintf(stderr, "called `Option::unwrap()` on a `None` value\n");
+            return 101;
+        }
+        rc = smafa_cluster(input, max_div, 1, (int)device, alphabet);
+    } else if (cmd == "count") {
+        if (count_paths.empty()) return usage("count needs --input");
+        rc = smafa_count(count_paths.data(), count_paths.size(), 1);
+    } else {
+        return usage(("unrecognized subcommand " + cmd).c_str());
+    }
+    if (rc != SMAFA_OK) {
+        fprintf(stderr, "%s\n", smafa_last_error());
+        return rc == SMAFA_ERR_PANIC ? 101 : 1;
+    }
+    return 0;
+}

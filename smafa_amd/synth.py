@@ -1,0 +1,60 @@
+"""Synthetic workloads of SURVEY.md §8(d) (fixed seeds; numpy PCG64).
+
+Subjects: n rows of `seq_len` symbols uniform over the alphabet's letters, 1 % of the rows
+overwritten with copies of earlier rows (ties / multiple minima).  Queries: a uniformly drawn subject
+with s substitutions at distinct positions, each to a different letter, s uniform in 0..max_subs — so a
+query has a hit within divergence D iff s <= D (random 60-mers are far apart).
+Returns CODE bytes (what crosses the C ABI) and the letters used.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+AA_LETTERS = b"ACDEFGHIKLMNPQRSTVWY"
+NT_LETTERS = b"ACGT"
+
+
+def letter_codes(alphabet: int) -> np.ndarray:
+    """code bytes of the letters the generators draw from (AA: 'A'..'Z' -> 0..25; NT: ACGT -> 0..3)"""
+    if alphabet == 1:
+        return np.frombuffer(AA_LETTERS, dtype=np.uint8) - ord("A")
+    return np.arange(4, dtype=np.uint8)
+
+
+def subjects(n: int, seq_len: int = 60, alphabet: int = 1, seed: int = 1, dup_frac: float = 0.01,
+             n_frac: float = 0.0) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    lc = letter_codes(alphabet)
+    out = lc[rng.integers(0, len(lc), size=(n, seq_len), dtype=np.uint8)]
+    if n_frac > 0 and alphabet == 0:  # nucleotide variant B: each column -> N with probability n_frac
+        out[rng.random(size=out.shape) < n_frac] = 4
+    n_dup = int(n * dup_frac)
+    if n_dup and n > 1:
+        dst = rng.integers(1, n, size=n_dup)
+        src = (rng.random(size=n_dup) * dst).astype(np.int64)  # an EARLIER row
+        out[dst] = out[src]
+    return out
+
+
+def queries(subject_codes: np.ndarray, q: int, alphabet: int = 1, seed: int = 3, max_subs: int = 10):
+    """-> (query codes, planted subject row, number of substitutions)"""
+    rng = np.random.default_rng(seed)
+    n, L = subject_codes.shape
+    lc = letter_codes(alphabet)
+    rows = rng.integers(0, n, size=q)
+    out = subject_codes[rows].copy()
+    subs = rng.integers(0, max_subs + 1, size=q)
+    # distinct positions: the first s entries of a random permutation per query
+    perm = np.argsort(rng.random(size=(q, L)), axis=1)
+    shift = rng.integers(1, len(lc), size=(q, L))  # change to a DIFFERENT letter of the generator's set
+    inv = np.full(256, 0, dtype=np.int64)
+    inv[lc] = np.arange(len(lc))
+    for i in range(q):
+        pos = perm[i, : subs[i]]
+        cur = out[i, pos]
+        ok = cur < 255
+        idx = inv[cur]
+        new = lc[(idx + shift[i, pos]) % len(lc)]
+        # a column holding a symbol outside the generator's set (an N) is replaced by a letter: still a change
+        out[i, pos] = np.where(np.isin(cur, lc) & ok, new, lc[shift[i, pos] % len(lc)])
+    return out, rows, subs

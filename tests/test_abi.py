@@ -1,0 +1,189 @@
+"""CPU-side tests of the product: the C-ABI library loads and exports every declared symbol, the host
+logic (encoding tables, DB file, FASTX reader, selection rules, CLI plumbing) matches the oracle and the
+reference's golden vectors, and GPU entry points fail loudly without a device.  No compute calls here."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+import smafa_amd
+from smafa_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    smafa_amd.build()
+
+
+def cli(*args):
+    return subprocess.run([_lib.CLI_PATH, *args], capture_output=True, text=True)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "smafa_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(smafa_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    l = _lib.lib()
+    for name in declared:
+        assert hasattr(l, name), name
+
+
+def test_encode_tables_match_oracle():
+    for alphabet in (smafa_amd.ALPHABET_NT, smafa_amd.ALPHABET_AA):
+        for b in range(256):
+            want = oracle.lib().orc_code(alphabet, b)
+            if want == 255:
+                with pytest.raises(smafa_amd.SmafaPanic):
+                    smafa_amd.encode(bytes([b]), alphabet)
+            else:
+                assert smafa_amd.encode(bytes([b]), alphabet)[0] == want
+    assert smafa_amd.decode(smafa_amd.encode(b"ACGTURYKM-nacgtu"), smafa_amd.ALPHABET_NT) == b"ACGTTNNNNNNACGTT"
+    assert smafa_amd.decode(smafa_amd.encode(b"acdeXZ*-", 1), 1) == b"ACDEXZ*-"
+
+
+@pytest.mark.parametrize("name", ["random_3_2.fna", "random_3_2_one_repeated.fna"])
+def test_makedb_bytes_match_reference_db(golden, tmp_path, name):
+    db = tmp_path / "t.db"
+    smafa_amd.makedb(os.path.join(golden, name), str(db))
+    assert db.read_bytes() == open(os.path.join(golden, name + ".smafadb"), "rb").read()
+
+
+def test_makedb_subjects_unit(golden, tmp_path):
+    # src/lib.rs:334-367
+    db = tmp_path / "s.db"
+    smafa_amd.makedb(os.path.join(golden, "subjects.fa"), str(db))
+    assert db.read_bytes() == bytes([2, 5, 1, 16, 1, 8, 1, 4, 1, 2, 1, 1, 1, 1])
+    alphabet, codes = smafa_amd.read_db(str(db))
+    assert alphabet == 0 and codes.tolist() == [[0], [1], [2], [3], [4]]
+
+
+def test_makedb_equals_oracle_makedb_on_random_fasta(tmp_path):
+    rng = np.random.default_rng(5)
+    letters = np.frombuffer(b"ACGTUNRYKMacgtn-", dtype=np.uint8)
+    for L in (1, 12, 13, 60, 61, 130):
+        rows = letters[rng.integers(0, len(letters), size=(50, L))]
+        f = tmp_path / f"r{L}.fna"
+        with open(f, "wb") as fh:  # multi-line FASTA with CRLF on some lines
+            for i, r in enumerate(rows):
+                fh.write(b">s%d some description\r\n" % i)
+                b = bytes(r)
+                fh.write(b[: L // 2] + b"\r\n" + b[L // 2:] + b"\n")
+        a, b = tmp_path / "a.db", tmp_path / "b.db"
+        smafa_amd.makedb(str(f), str(a))
+        assert oracle.run_cli("makedb", "-i", str(f), "-d", str(b)).returncode == 0
+        assert a.read_bytes() == b.read_bytes()
+        alphabet, codes = smafa_amd.read_db(str(a))
+        assert (codes == oracle.codes_from_ascii(rows, 0)).all()
+
+
+def test_dbfile_roundtrip_aa(tmp_path):
+    rng = np.random.default_rng(6)
+    codes = rng.integers(0, 28, size=(100, 60), dtype=np.uint8)
+    p = tmp_path / "aa.db"
+    smafa_amd.write_db(str(p), codes, smafa_amd.ALPHABET_AA)
+    alphabet, back = smafa_amd.read_db(str(p))
+    assert alphabet == 1 and (back == codes).all()
+    # the reference's version gate rejects it, as the oracle restates (src/lib.rs:215-217)
+    r = oracle.run_cli("query", "-d", str(p), "-q", os.path.join(ROOT, "tests/golden/random_3_2.fna"))
+    assert r.returncode != 0 and "Unsupported db file version: 3." in r.stderr
+
+
+def test_old_db_version_message(golden):
+    # tests/test_cmdline.rs:28-41 — fails before any device work
+    r = cli("query", "-d", os.path.join(golden, "random_3_2.fna.v1.smafadb"), "-q", os.path.join(golden, "random_3_2.fna"))
+    assert r.returncode == 101 and "Unsupported db file version: 1." in r.stderr and r.stdout == ""
+
+
+def test_count_cli(golden):
+    # tests/test_cmdline.rs:184-201
+    for name, reads, bases in (("random_3_2.fna", 2, 6), ("random_30_4.fq.gz", 4, 120)):
+        p = os.path.join(golden, name)
+        r = cli("count", "-i", p)
+        assert r.returncode == 0
+        assert r.stdout == '[{"path":"%s","num_reads":%d,"num_bases":%d}]\n' % (p, reads, bases)
+
+
+def test_bad_input_messages(tmp_path):
+    f = tmp_path / "bad.fna"
+    f.write_bytes(b">seq one\nACGTACGTACGTAE\n")
+    r = cli("makedb", "-i", str(f), "-d", str(tmp_path / "x.db"))
+    assert r.returncode == 101
+    assert 'Byte 69 cannot be interpreted as nucleotide, in sequence "seq one" at position 13' in r.stderr
+    f.write_bytes(b">a\nACGT\n>b\nACG\n")
+    r = cli("makedb", "-i", str(f), "-d", str(tmp_path / "x.db"))
+    assert r.returncode == 101 and "WindowSet seq length is 4, got a new sequence of length 3" in r.stderr
+    r = cli("cluster", "-i", str(f))
+    assert r.returncode == 101  # src/main.rs:43 unwraps --max-divergence
+
+
+def _oracle_rows(text):
+    return [tuple(l.split("\t")) for l in text.splitlines()]
+
+
+@pytest.mark.parametrize("flags", [
+    (None, None, None), (5, None, None), (None, 3, None), (4, 3, None), (None, 99999, None), (6, 5, 1), (None, 7, 2),
+    (0, None, None), (0, 2, None), (60, 4, 1),
+])
+def test_select_rows_equals_oracle_query(flags):
+    """product selection (host) on oracle-made hit lists == oracle's full query output"""
+    max_div, max_hits, limit = flags
+    rng = np.random.default_rng(hash(flags) % 1000)
+    L, n, q = 24, 400, 40
+    codes = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    codes[50:80] = codes[10]                     # many identical subjects (ties, limit-per-sequence)
+    codes[100:120, :20] = codes[10, :20]         # near copies
+    qcodes = codes[rng.integers(0, n, size=q)].copy()
+    for r in qcodes:
+        for _ in range(rng.integers(0, 6)):
+            r[rng.integers(0, L)] = rng.integers(0, 4)
+    ascii_s = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+    ascii_q = np.frombuffer(b"ACGT", dtype=np.uint8)[qcodes]
+    args = []
+    if max_div is not None:
+        args += ["--max-divergence", str(max_div)]
+    if max_hits is not None:
+        args += ["--max-num-hits", str(max_hits)]
+    if limit is not None:
+        args += ["--limit-per-sequence", str(limit)]
+    want = oracle.query_text([bytes(r) for r in ascii_s], [bytes(r) for r in ascii_q], *args)
+    # the hit list a scan would deliver: everything within max_div (the k-th bound is applied by select)
+    hits = oracle.scan_codes(codes, qcodes, L if max_div is None else max_div)
+    rows = smafa_amd.select_rows(hits, q, n, codes, L, max_div, max_hits, limit)
+    got = "".join("%d\t%d\t%d\t%s\n" % (r["query"], r["subject"], r["dist"], smafa_amd.decode(codes[r["subject"]]).decode())
+                  for r in rows)
+    assert got == want
+
+
+def test_select_rows_panics():
+    hits = np.zeros(1, dtype=smafa_amd.HIT_DTYPE)
+    codes = np.zeros((1, 4), dtype=np.uint8)
+    with pytest.raises(smafa_amd.SmafaPanic, match="limit_per_sequence is implemented unless"):
+        smafa_amd.select_rows(hits, 1, 1, codes, 4, None, None, 1)          # src/lib.rs:301-303
+    with pytest.raises(smafa_amd.SmafaPanic, match="index out of bounds"):
+        smafa_amd.select_rows(hits, 1, 1, codes, 4, None, 0, None)          # src/lib.rs:255
+    with pytest.raises(smafa_amd.SmafaPanic, match="Option::unwrap"):
+        smafa_amd.select_rows(hits[:0], 1, 0, None, 4, None, None, None)    # src/lib.rs:298 on an empty store
+
+
+def test_scan_fails_loudly_without_gpu(golden):
+    if smafa_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(smafa_amd.SmafaError, match="no CPU fallback"):
+        smafa_amd.SubjectStore(60)
+    r = cli("query", "-d", os.path.join(golden, "random_3_2.fna.smafadb"), "-q", os.path.join(golden, "random_3_2.fna"))
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr and r.stdout == ""
+
+
+def test_synth_queries_have_planted_distance():
+    from smafa_amd import synth
+    for alphabet, ms in ((1, 10), (0, 6)):
+        s = synth.subjects(2000, 60, alphabet, seed=1)
+        q, rows, subs = synth.queries(s, 200, alphabet, seed=3, max_subs=ms)
+        d = (s[rows] != q).sum(axis=1)
+        assert (d == subs).all()

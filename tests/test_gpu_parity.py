@@ -1,0 +1,366 @@
+"""GPU parity: the HIP path, called through the C ABI (ctypes) and the `smafa` CLI, against the CPU
+oracle on the same seeded inputs — bit-exact (integer work), same rows, same order.
+
+Sizes here are ones the oracle finishes in seconds; the full BASELINE sizes are covered by
+size-independent properties in test_gpu_fullsize.py.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+import smafa_amd
+from smafa_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+NT_ASCII = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    smafa_amd.build()
+    assert smafa_amd.device_count() >= 1, "GPU tests need a HIP device (no CPU fallback exists)"
+
+
+def planted(rng, n, L, n_letters, q, max_subs, dup=True):
+    s = rng.integers(0, n_letters, size=(n, L), dtype=np.uint8)
+    if dup and n > 4:
+        s[n // 2] = s[1]
+        s[n - 1] = s[1]
+    qs = s[rng.integers(0, n, size=q)].copy()
+    for r in qs:
+        for _ in range(rng.integers(0, max_subs + 1)):
+            r[rng.integers(0, L)] = rng.integers(0, n_letters)
+    return s, qs
+
+
+def expected_with_k(all_hits, k):
+    """apply "dist <= k-th smallest distance of the query" to an ordered complete hit list"""
+    out = []
+    i = 0
+    while i < len(all_hits):
+        j = i
+        while j < len(all_hits) and all_hits[j]["query"] == all_hits[i]["query"]:
+            j += 1
+        grp = all_hits[i:j]
+        kth = grp[k - 1]["dist"] if len(grp) >= k else 0xFFFFFFFF
+        out.append(grp[grp["dist"] <= kth])
+        i = j
+    return np.concatenate(out) if out else all_hits[:0]
+
+
+# ------------------------------------------------------------------------------ scan vs oracle
+@pytest.mark.parametrize("alphabet,n_letters", [(0, 5), (1, 28)])
+@pytest.mark.parametrize("L", [1, 11, 31, 32, 33, 60, 64, 65, 96, 128, 129, 200])
+def test_scan_hits_equals_oracle(alphabet, n_letters, L):
+    rng = np.random.default_rng(1000 * alphabet + L)
+    for n in (1, 255, 256, 257, 1025, 3000):
+        s, q = planted(rng, n, L, n_letters, 70, min(L, 8))
+        store = smafa_amd.SubjectStore(L, alphabet)
+        store.push(s)
+        assert len(store) == n
+        for D in sorted({0, min(3, L), min(6, L), L}):
+            got = store.scan(q, max_divergence=D)
+            want = oracle.scan_codes(s, q, D)
+            assert got.tobytes() == want.tobytes(), (alphabet, L, n, D)
+        store.close()
+
+
+def test_nt_scan_equals_reference_arithmetic():
+    """NT path vs the reference's own arithmetic (5-bit one-hot, xor + popcount / 2) on ASCII input"""
+    rng = np.random.default_rng(2)
+    letters = np.frombuffer(b"ACGTUNRYKMacgtn-", dtype=np.uint8)
+    for L in (5, 12, 13, 60, 61):
+        subj = letters[rng.integers(0, len(letters), size=(2000, L))]
+        qry = subj[rng.integers(0, 2000, size=50)].copy()
+        for r in qry:
+            for _ in range(rng.integers(0, 5)):
+                r[rng.integers(0, L)] = letters[rng.integers(0, len(letters))]
+        store = smafa_amd.SubjectStore(L, smafa_amd.ALPHABET_NT)
+        store.push(smafa_amd.encode_rows(subj))
+        for D in (0, 4, L):
+            got = store.scan(smafa_amd.encode_rows(qry), max_divergence=D)
+            want = oracle.scan_onehot(subj, qry, D)
+            assert got.tobytes() == want.tobytes(), (L, D)
+        store.close()
+
+
+def test_aa_kernel_on_nucleotide_data_equals_reference_arithmetic():
+    """the 5-plane (amino-acid) kernel is the same code path; on nucleotide-alphabet data it must
+    reproduce the reference-pinned one-hot result (cross-pin of the unpinned extension)"""
+    rng = np.random.default_rng(3)
+    codes = rng.integers(0, 5, size=(3000, 60), dtype=np.uint8)
+    q = codes[rng.integers(0, 3000, size=64)].copy()
+    q[:, 7] = (q[:, 7] + 1) % 5
+    store = smafa_amd.SubjectStore(60, smafa_amd.ALPHABET_AA)  # AA store, codes 0..4 only
+    store.push(codes)
+    got = store.scan(q, max_divergence=5)
+    want = oracle.scan_onehot(NT_ASCII[codes], NT_ASCII[q], 5)
+    assert got.tobytes() == want.tobytes()
+    store.close()
+
+
+@pytest.mark.parametrize("alphabet,n_letters,L", [(0, 5, 60), (1, 28, 60), (0, 5, 7), (1, 28, 150)])
+def test_get_distances_equals_oracle(alphabet, n_letters, L):
+    rng = np.random.default_rng(4)
+    s, q = planted(rng, 2500, L, n_letters, 5, 6)
+    store = smafa_amd.SubjectStore(L, alphabet)
+    store.push(s)
+    for i in range(5):
+        assert (store.get_distances(q[i]) == oracle.distances_codes(s, q[i])).all()
+    store.close()
+
+
+def test_append_in_pieces_equals_single_push():
+    rng = np.random.default_rng(5)
+    s, q = planted(rng, 2100, 60, 28, 40, 6)
+    one = smafa_amd.SubjectStore(60, 1)
+    one.push(s)
+    pieces = smafa_amd.SubjectStore(60, 1)
+    at = 0
+    for step in (1, 62, 1, 64, 128, 300, 700, 3, 841):
+        pieces.push(s[at:at + step])
+        at += step
+    assert at == 2100 and len(pieces) == 2100
+    a = one.scan(q, max_divergence=8)
+    b = pieces.scan(q, max_divergence=8)
+    assert a.tobytes() == b.tobytes() == oracle.scan_codes(s, q, 8).tobytes()
+    one.close()
+    pieces.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 40])
+@pytest.mark.parametrize("max_div", [None, 4, 30])
+def test_kth_bound_modes(k, max_div):
+    """max_num_hits = k: rows within the k-th smallest distance (ties included), src/lib.rs:250-256;
+    exercises the seed + growing-segment launches that tighten the per-query bounds"""
+    rng = np.random.default_rng(6)
+    L = 60
+    s, q = planted(rng, 9000, L, 4, 80, 7)  # 4 letters: distances spread out, plenty of ties
+    s[100:140] = s[7]
+    store = smafa_amd.SubjectStore(L, 0)
+    store.push(s)
+    got = store.scan(q, max_divergence=max_div, max_num_hits=k)
+    full = oracle.scan_codes(s, q, L if max_div is None else max_div)
+    want = expected_with_k(full, k)
+    assert got.tobytes() == want.tobytes()
+    store.close()
+
+
+def test_capacity_error_reports_rows_needed():
+    rng = np.random.default_rng(7)
+    s, q = planted(rng, 500, 20, 4, 10, 2)
+    store = smafa_amd.SubjectStore(20, 0)
+    store.push(s)
+    want = oracle.scan_codes(s, q, 20)
+    assert len(want) == 5000
+    out = np.zeros(10, dtype=smafa_amd.HIT_DTYPE)
+    n_out = C.c_uint64(0)
+    rc = _lib.lib().smafa_scan_hits(store._h, q.ctypes.data, 10, 20, _lib.NONE, out.ctypes.data, 10, C.byref(n_out))
+    assert rc == _lib.ERR_CAPACITY and n_out.value == 5000
+    store.close()
+
+
+def test_dense_hits_overflow_path():
+    """every pair qualifies: more rows than the device scratch holds -> query range is split"""
+    rng = np.random.default_rng(8)
+    s = rng.integers(0, 4, size=(70000, 16), dtype=np.uint8)
+    q = rng.integers(0, 4, size=(100, 16), dtype=np.uint8)
+    store = smafa_amd.SubjectStore(16, 0)
+    store.push(s)
+    got = store.scan(q, max_divergence=16)  # 7M rows > 4M scratch rows
+    assert len(got) == 70000 * 100
+    d = (s[got["subject"][::997]] != q[got["query"][::997]]).sum(axis=1)
+    assert (d == got["dist"][::997]).all()
+    key = got["query"].astype(np.int64) << 40 | got["dist"].astype(np.int64) << 32 | got["subject"]
+    assert (np.diff(key) > 0).all()
+    store.close()
+
+
+# ------------------------------------------------------------------------- CLI: golden vectors
+def cli(*args):
+    return subprocess.run([_lib.CLI_PATH, *args], capture_output=True, text=True)
+
+
+def rows(*r):
+    return "".join("\t".join(map(str, x)) + "\n" for x in r)
+
+
+FOUR = rows((0, 0, 0, "CTT"), (0, 1, 3, "AGG"), (1, 1, 0, "AGG"), (1, 0, 3, "CTT"))
+TWO = rows((0, 0, 0, "CTT"), (1, 1, 0, "AGG"))
+
+
+def test_golden_dna_makedb_and_query(golden, tmp_path):  # tests/test_cmdline.rs:10-25
+    db = str(tmp_path / "t.db")
+    f = os.path.join(golden, "random_3_2.fna")
+    assert cli("makedb", "-i", f, "-d", db).returncode == 0
+    r = cli("query", "-d", db, "-q", f)
+    assert r.returncode == 0 and r.stdout == TWO
+
+
+def test_golden_degenerate(golden, tmp_path):  # tests/test_cmdline.rs:44-74
+    db = str(tmp_path / "t.db")
+    f = os.path.join(golden, "degenerate.fna")
+    assert cli("makedb", "-i", f, "-d", db).returncode == 0
+    r = cli("query", "-d", db, "-q", f, "--max-num-hits", "99")
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == rows(
+        (0, 0, 0, "CTTNGG"), (0, 1, 5, "AGGTGA"), (0, 2, 6, "NACTTT"),
+        (1, 1, 0, "AGGTGA"), (1, 0, 5, "CTTNGG"), (1, 2, 5, "NACTTT"),
+        (2, 2, 0, "NACTTT"), (2, 1, 5, "AGGTGA"), (2, 0, 6, "CTTNGG"))
+
+
+@pytest.mark.parametrize("flags,expected", [
+    (["--max-divergence", "99", "--max-num-hits", "99"], FOUR),  # test_cmdline.rs:77-97
+    (["--max-divergence", "2", "--max-num-hits", "99"], TWO),    # :100-118
+    (["--max-divergence", "3", "--max-num-hits", "99"], FOUR),   # :121-141
+    (["--max-num-hits", "1"], TWO),                              # :144-160
+    (["--max-num-hits", "99"], FOUR),                            # :163-181
+])
+def test_golden_prebuilt_db(golden, flags, expected):
+    r = cli("query", "-d", os.path.join(golden, "random_3_2.fna.smafadb"), "-q", os.path.join(golden, "random_3_2.fna"), *flags)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == expected
+
+
+def test_golden_limit_per_sequence(golden):  # tests/test_cmdline.rs:204-247
+    db = os.path.join(golden, "random_3_2_one_repeated.fna.smafadb")
+    q = os.path.join(golden, "random_3_2.fna")
+    r = cli("query", "-d", db, "-q", q, "--max-num-hits", "99")
+    assert r.stdout == rows((0, 0, 0, "CTT"), (0, 1, 3, "AGG"), (0, 2, 3, "AGG"), (1, 1, 0, "AGG"), (1, 2, 0, "AGG"), (1, 0, 3, "CTT"))
+    r = cli("query", "-d", db, "-q", q, "--max-num-hits", "99", "--limit-per-sequence", "1")
+    assert r.stdout == FOUR
+    r = cli("query", "-d", db, "-q", q, "--limit-per-sequence", "1")  # src/lib.rs:301-303
+    assert r.returncode == 101 and "limit_per_sequence is implemented unless" in r.stderr
+
+
+def test_golden_cluster(golden):  # src/cluster.rs:102-143
+    r = cli("cluster", "-i", os.path.join(golden, "cluster_dummy1.fna"), "-d", "1")
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == "ATGC\tATGC\nATGG\tATGC\nAAAA\tAAAA\n"
+    for name in ("cluster_bug1.fna", "cluster_best_hit_changes.fna"):
+        r = cli("cluster", "-i", os.path.join(golden, name), "-d", "2")
+        assert r.stdout == "ATGCAAAAA\tATGCAAAAA\nATAAAAAAA\tATGCAAAAA\nTTAAAAAAA\tTTAAAAAAA\n"
+
+
+# ------------------------------------------------------------- CLI: differential vs oracle CLI
+def write_fasta(path, ascii_rows, fastq=False):
+    with open(path, "wb") as f:
+        for i, r in enumerate(ascii_rows):
+            b = bytes(r)
+            if fastq:
+                f.write(b"@r%d\n" % i + b + b"\n+\n" + b"I" * len(b) + b"\n")
+            else:
+                f.write(b">r%d desc\n" % i + b[:25] + b"\n" + b[25:] + b"\n")
+
+
+@pytest.mark.parametrize("flags", [
+    [], ["--max-divergence", "5"], ["--max-divergence", "0"], ["--max-num-hits", "4"],
+    ["--max-num-hits", "4", "--max-divergence", "6"], ["--max-num-hits", "100000"],
+    ["--max-num-hits", "6", "--limit-per-sequence", "2"], ["--max-num-hits", "3", "--max-divergence", "60"],
+])
+def test_query_cli_equals_oracle_cli(tmp_path, flags):
+    rng = np.random.default_rng(9)
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    s = letters[rng.integers(0, 4, size=(4000, 60))]
+    s[rng.random(size=s.shape) < 0.01] = ord("N")
+    s[300:330] = s[5]
+    s[400:420, :55] = s[5, :55]
+    q = s[rng.integers(0, 4000, size=150)].copy()
+    for r in q:
+        for _ in range(rng.integers(0, 8)):
+            r[rng.integers(0, 60)] = letters[rng.integers(0, 5)]
+    sf, qf, db = str(tmp_path / "s.fna"), str(tmp_path / "q.fq"), str(tmp_path / "db")
+    write_fasta(sf, s)
+    write_fasta(qf, q, fastq=True)
+    assert cli("makedb", "-i", sf, "-d", db).returncode == 0
+    got = cli("query", "-d", db, "-q", qf, *flags)
+    want = oracle.run_cli("query", "-d", db, "-q", qf, *flags)
+    assert got.returncode == 0 and want.returncode == 0, (got.stderr, want.stderr)
+    assert got.stdout == want.stdout
+    assert len(got.stdout) > 0
+
+
+def test_query_cli_error_after_partial_output(tmp_path):
+    """a bad query record: rows of the earlier queries are printed, then the reference's panic text"""
+    sf, qf, db = str(tmp_path / "s.fna"), str(tmp_path / "q.fna"), str(tmp_path / "db")
+    open(sf, "wb").write(b">a\nACGTACGT\n>b\nTTTTACGT\n")
+    open(qf, "wb").write(b">q0\nACGTACGT\n>q1\nACGTAEGT\n>q2\nTTTTACGT\n")
+    assert cli("makedb", "-i", sf, "-d", db).returncode == 0
+    got = cli("query", "-d", db, "-q", qf)
+    want = oracle.run_cli("query", "-d", db, "-q", qf)
+    assert got.returncode == 101 and want.returncode == 101
+    assert got.stdout == want.stdout == "0\t0\t0\tACGTACGT\n"
+    assert 'Byte 69 cannot be interpreted as nucleotide, in sequence "q1" at position 5' in got.stderr
+    open(qf, "wb").write(b">q0\nACGTACGT\n>q1\nACGTACG\n")
+    got = cli("query", "-d", db, "-q", qf)
+    assert got.returncode == 101 and got.stdout == "0\t0\t0\tACGTACGT\n"
+    assert "Cannot compute distances between seq of length 7 and windows of lengths 8" in got.stderr
+
+
+def clustered(rng, n_roots, members, L, n_letters, max_subs):
+    roots = rng.integers(0, n_letters, size=(n_roots, L), dtype=np.uint8)
+    recs = np.repeat(roots, members, axis=0)
+    for r in recs:
+        for _ in range(rng.integers(0, max_subs + 1)):
+            r[rng.integers(0, L)] = rng.integers(0, n_letters)
+    rng.shuffle(recs, axis=0)
+    return recs
+
+
+@pytest.mark.parametrize("D", [0, 2, 5, 9])
+def test_cluster_cli_equals_oracle_cli(tmp_path, D):
+    rng = np.random.default_rng(10 + D)
+    recs = clustered(rng, 300, 20, 60, 4, 4)  # 6000 records, several batches, duplicates included
+    ascii_rows = NT_ASCII[recs]
+    lower = ascii_rows.copy()
+    lower[::3] = np.char.lower(lower[::3].view("S1")).view(np.uint8)  # column 1 must echo the raw bytes
+    f = str(tmp_path / "c.fna")
+    with open(f, "wb") as fh:
+        for i, r in enumerate(lower):
+            fh.write(b">c%d\n" % i + bytes(r) + b"\n")
+    got = cli("cluster", "-i", f, "-d", str(D))
+    want = oracle.run_cli("cluster", "-i", f, "-d", str(D))
+    assert got.returncode == 0 and want.returncode == 0, got.stderr
+    assert got.stdout == want.stdout
+    assert got.stdout.count("\n") > 1000
+
+
+def test_cluster_aa_equals_oracle_codes(tmp_path):
+    rng = np.random.default_rng(20)
+    lc = synth.letter_codes(1)
+    recs = lc[clustered(rng, 200, 25, 60, 20, 5)]
+    assigned = oracle.cluster_codes(recs, 5, oracle.ALPHABET_AA)
+    letters = np.array([ord(smafa_amd.decode(np.array([c], dtype=np.uint8), 1)) for c in range(28)], dtype=np.uint8)
+    ascii_rows = letters[recs]
+    f = str(tmp_path / "aa.faa")
+    with open(f, "wb") as fh:
+        for i, r in enumerate(ascii_rows):
+            fh.write(b">p%d\n" % i + bytes(r) + b"\n")
+    got = cli("cluster", "-i", f, "-d", "5", "--alphabet", "aa")
+    assert got.returncode == 0, got.stderr
+    cents, lines = [], []
+    for i, a in enumerate(assigned):
+        if a == 0xFFFFFFFF:
+            continue
+        if a == len(cents):
+            cents.append(bytes(ascii_rows[i]))
+        lines.append(bytes(ascii_rows[i]) + b"\t" + cents[a] + b"\n")
+    assert got.stdout.encode() == b"".join(lines)
+
+
+def test_python_api_query_and_cluster(golden, tmp_path):
+    """the ctypes mirror of the crate's pub fns writes the same bytes as the CLI"""
+    out = tmp_path / "out.tsv"
+    fd = os.open(str(out), os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    try:
+        smafa_amd.query(os.path.join(golden, "random_3_2.fna.smafadb"), os.path.join(golden, "random_3_2.fna"),
+                        max_divergence=99, max_num_hits=99, out_fd=fd)
+        smafa_amd.cluster(os.path.join(golden, "cluster_dummy1.fna"), 1, out_fd=fd)
+    finally:
+        os.close(fd)
+    assert out.read_text() == FOUR + "ATGC\tATGC\nATGG\tATGC\nAAAA\tAAAA\n"
