@@ -35,6 +35,7 @@ struct smafa_db {
     bool timed = false;
     uint32_t last_launches = 0;
     uint32_t qb_override = 0;
+    bool use_filter = true;  // exact lower-bound prefilter in the scan kernel (SMAFA_FILTER=0 disables)
     int n_cu = 256;
     // scratch of the host-buffer scan API, kept across calls
     smafa_hit *d_hits = nullptr;
@@ -160,6 +161,7 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     a.cnt = qs->d_cnt;
     a.cnt_stride = db->L + 1;
     a.k_tight = k_tight;
+    a.use_filter = db->use_filter ? 1u : 0u;
     a.hits = d_hits;
     a.cap = cap;
     a.count = d_count;
@@ -340,7 +342,8 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     db->L = seq_len;
     db->P = (uint32_t)planes_for(alphabet);
     db->W = (seq_len + 31) / 32;
-    db->QS = (uint32_t)round_up4((int)(db->P * db->W));
+    db->QS = (uint32_t)qrec_stride((int)db->P, (int)db->W);
+    if (const char *fv = getenv("SMAFA_FILTER")) db->use_filter = atoi(fv) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) db->n_cu = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&db->own_stream, hipStreamNonBlocking);

@@ -18,10 +18,18 @@
 // lane, 1 KiB contiguous per wave instruction, and the whole tile (P*W KiB) is read exactly once
 // per query block and then lives in VGPRs while the wave walks the query block.
 //
-// Queries are wave-uniform: a query record (P*W words, padded to QS) is fetched with scalar
-// loads into SGPRs and used as the scalar operand of v_bitop3 — no LDS or VGPR traffic at all
-// for the query side.  Hits are rare (thresholded), so the append is a wave-aggregated atomic
-// (v_mbcnt + s_bcnt1 + one global_atomic_add per wave, emitted by hipcc for atomicAdd(p, 1)).
+// Query records (u32 words, stride qrec_stride(P, W)):
+//     [ filter-plane words 0..W-1 | bound slot | the other planes' words ]
+// The 4 waves of a workgroup walk the same query block, so they stage 64 records at a time in LDS
+// (double-buffered, one barrier per 64 queries) and every wave broadcast-reads a record into VGPRs with
+// ds_read_b128 (all lanes read one address: conflict-free).  Why not scalar registers: measured on
+// MI355X (profiles/r01_ubench_valu*.txt) v_xor / v_add / v_bitop3 with all-VGPR sources issue at
+// ~60 T lane-ops/s chip-wide, while the same ops with an SGPR source — and v_bcnt, v_min, v_cmp, v_or3
+// regardless of sources — issue at ~37 T.  The hot loop is therefore built from all-VGPR bitop3/xor,
+// as few popcounts as exactness allows, and a single compare per wave step.
+//
+// Hits are rare (thresholded), so the append is a wave-aggregated atomic (v_mbcnt + s_bcnt1 + one
+// global_atomic_add per wave, emitted by hipcc for atomicAdd(p, 1)).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -34,24 +42,32 @@ namespace smafa {
 constexpr int kWaveTile = 256;  // subjects per wave tile
 constexpr int kWgWaves = 4;     // waves per workgroup
 constexpr int kWgTile = kWaveTile * kWgWaves;
+constexpr int kChunk = 64;      // queries staged in LDS at a time
 
 __host__ __device__ constexpr int round_up4(int x) { return (x + 3) & ~3; }
-// query record stride in u32 words
-__host__ __device__ constexpr int qrec_stride(int planes, int words) { return round_up4(planes * words); }
+// query record stride in u32 words: the plane words plus the bound slot, rounded up to whole uint4s
+__host__ __device__ constexpr int qrec_stride(int planes, int words) { return round_up4(planes * words + 1); }
+// The plane the prefilter looks at.  Nucleotide codes are A=0 C=1 G=2 T=3 N=4: bit 1 separates {A,C} from
+// {G,T}, so it sees both transitions (A<->G, C<->T), the commonest real substitutions; bit 0 would miss them.
+__host__ __device__ constexpr int filter_plane(int planes) { return planes == 3 ? 1 : 0; }
+// slot of word w of plane p inside a record
+__host__ __device__ constexpr int qslot(int planes, int words, int p, int w) {
+    return p == filter_plane(planes) ? w : words + 1 + (p < filter_plane(planes) ? p : p - 1) * words + w;
+}
+__host__ __device__ constexpr int bound_slot(int words) { return words; }
 
-// planes / qrec are passed as separate `const __restrict__` kernel parameters (not in this struct) so
-// that hipcc can prove the query records are never clobbered and fetch them with scalar loads.
 struct ScanArgs {
     uint32_t tile_begin, tile_end;  // wave-tile range of this launch
     uint32_t n_wg_tiles;            // ceil((tile_end - tile_begin) / 4)
     uint32_t n_subjects;
     uint32_t q_begin, q_end;  // query range of this launch
     uint32_t qb_size;         // queries per workgroup pass
-    uint32_t *thr;            // per-query emission threshold (only ever lowered)
+    uint32_t *thr;            // per-query emission bound (only ever lowered)
     uint32_t *cnt;            // per-query histogram of emitted distances (k_tight >= 2), stride cnt_stride
     uint32_t cnt_stride;
-    uint32_t k_tight;         // 0: thresholds fixed; 1: lower to running minimum; k>=2: lower to running k-th
-    smafa_hit *hits;          // NULL: seed pass — tighten thresholds, append nothing
+    uint32_t k_tight;         // 0: bounds fixed; 1: lower to running minimum; k>=2: lower to running k-th
+    uint32_t use_filter;      // 0: always the full comparison; 1: prefilter with per-wave fallback
+    smafa_hit *hits;          // NULL: seed pass — tighten bounds, append nothing
     unsigned long long cap;
     unsigned long long *count;
 };
@@ -60,14 +76,18 @@ struct ScanArgs {
 __device__ __forceinline__ uint32_t or_xor(uint32_t acc, uint32_t s, uint32_t q) {
     return __builtin_amdgcn_bitop3_b32(acc, s, q, 0xF6);
 }
+// a | b | c through the fast bitop3 path (v_or3_b32 itself issues at the slow rate)
+__device__ __forceinline__ uint32_t or3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE);
+}
 
 __device__ __forceinline__ uint32_t ld_relaxed(const uint32_t *p) {
-    // agent-scope relaxed load: bypasses the non-coherent caches, so a threshold lowered by a
-    // workgroup on another XCD is seen (a stale, higher value would still be correct — see emit()).
+    // agent-scope relaxed load: bypasses the non-coherent caches, so a bound lowered by a workgroup on
+    // another XCD is seen (a stale, higher value would still be correct — see emit()).
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Rare path: append one qualifying pair and, when asked, tighten the query's threshold.
+// Rare path: append one qualifying pair and, when asked, tighten the query's bound.
 // Correctness of tightening: thr[q] is only lowered to a distance d once at least k subjects with
 // distance <= d have been counted, so thr[q] >= (k-th smallest distance of q) at all times and every
 // subject within the true bound passes `dist <= thr` whenever it is visited.
@@ -93,63 +113,173 @@ __device__ __forceinline__ void emit(const ScanArgs &a, uint32_t q, uint32_t sub
     }
 }
 
+template <int K>
+__device__ __forceinline__ uint32_t comp(const uint4 &v) {
+    return K == 0 ? v.x : K == 1 ? v.y : K == 2 ? v.z : v.w;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The scan: one workgroup = 4 waves = 1024 subjects x one block of queries.
+//
+// Per (query, 4 subjects of a lane) the wave first evaluates an exact LOWER BOUND of the distance:
+//     lb = popcount( OR_w ( S_f[w] XOR Q_f[w] ) )           f = filter plane
+// Every set bit of that OR is a column (in at least one 32-column word) whose filter-plane bits
+// differ, i.e. a mismatching column, and distinct bits are distinct columns within a word, so
+// lb <= distance.  The record carries ~bound, and v_bcnt's accumulator adds it for free:
+//     popcount(m) + ~bound  <  0   <=>   popcount(m) <= bound
+// so "can any of my 4 subjects still qualify" is the sign bit of an OR of four popcounts and costs
+// one compare per wave step.  Only when some lane says yes does the wave compute the full distance
+// for that query (all planes, all words) and test it exactly.  Nothing is approximated: a pair is
+// skipped only when its lower bound already exceeds the query's bound.
+// If the prefilter stops paying (dense neighbourhoods: it passes for more than a quarter of a chunk's
+// queries) the wave switches to the plain full comparison and re-probes every 16th chunk.
 // ---------------------------------------------------------------------------------------------
 template <int P, int W>
 __global__ __launch_bounds__(256) void scan_kernel(const uint4 *__restrict__ planes,
                                                    const uint32_t *__restrict__ qrec, ScanArgs a) {
-    constexpr int QS = qrec_stride(P, W);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    constexpr int RS = qrec_stride(P, W);  // words per record
+    constexpr int RV = RS / 4;             // uint4 per record
+    constexpr int NV = (kChunk * RV + 255) / 256;
+    constexpr int FP = filter_plane(P);
+    constexpr int BS = bound_slot(W);
+    constexpr int HV = (W + 1 + 3) / 4;  // uint4s holding the filter words + bound slot
+    __shared__ uint4 stage[2][kChunk * RV];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
     const uint32_t wg_tile = blockIdx.x % a.n_wg_tiles;  // tiles fastest: all CUs share one query block
     const uint32_t qblock = blockIdx.x / a.n_wg_tiles;
     const uint32_t tile = a.tile_begin + wg_tile * kWgWaves + wave;
-    if (tile >= a.tile_end) return;  // whole wave exits; the kernel has no barrier
+    const bool active = tile < a.tile_end;  // idle waves still take part in staging and barriers
 
     uint4 s[P * W];
     {
-        const uint4 *t = planes + (size_t)tile * (P * W * 64) + lane;
+        const uint4 *t = planes + (size_t)(active ? tile : a.tile_begin) * (P * W * 64) + lane;
 #pragma unroll
         for (int i = 0; i < P * W; i++) s[i] = t[i * 64];
     }
     const uint32_t subj0 = tile * kWaveTile + lane * 4u;
-
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
     const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
 
-    for (uint32_t qc = q0; qc < q1; qc += 64) {
-        const uint32_t nqc = min(64u, q1 - qc);
-        // thresholds of the next 64 queries, one per lane, read with one coalesced load
-        const uint32_t thr_v = lane < nqc ? ld_relaxed(a.thr + qc + lane) : 0u;
-        const uint32_t *qr = qrec + (size_t)qc * QS;  // wave-uniform -> scalar loads
-        for (uint32_t i = 0; i < nqc; i++, qr += QS) {
-            const uint32_t U = __builtin_amdgcn_readlane(thr_v, i);
-            uint32_t d[4];
+    uint4 pre[NV];
+    auto fetch = [&](uint32_t qc) {  // global -> registers: this thread's share of chunk [qc, qc+64)
+        const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
+        const uint4 *src = reinterpret_cast<const uint4 *>(qrec + (size_t)qc * RS);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t acc = 0;
-#pragma unroll
-                for (int w = 0; w < W; w++) {
-                    uint32_t m = 0;
-#pragma unroll
-                    for (int p = 0; p < P; p++) {
-                        const uint4 v = s[p * W + w];
-                        const uint32_t sv = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
-                        const uint32_t qv = qr[p * W + w];
-                        m = (p == 0) ? (sv ^ qv) : or_xor(m, sv, qv);
-                    }
-                    acc += __builtin_popcount(m);
+        for (int v = 0; v < NV; v++) {
+            const uint32_t idx = tid + v * 256;
+            if (idx < nqc * RV) {
+                uint4 x = src[idx];
+                if (idx % RV == BS / 4) {  // the uint4 holding the bound slot: merge ~bound
+                    const uint32_t nu = ~ld_relaxed(a.thr + qc + idx / RV);
+                    if ((BS & 3) == 0) x.x = nu;
+                    else if ((BS & 3) == 1) x.y = nu;
+                    else if ((BS & 3) == 2) x.z = nu;
+                    else x.w = nu;
                 }
-                d[k] = acc;
-            }
-            const uint32_t dmin = min(min(d[0], d[1]), min(d[2], d[3]));
-            if (dmin <= U) {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, qc + i, subj0 + k, d[k]);
+                pre[v] = x;
             }
         }
+    };
+    auto commit = [&](int buf, uint32_t qc) {  // registers -> LDS
+        const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const uint32_t idx = tid + v * 256;
+            if (idx < nqc * RV) stage[buf][idx] = pre[v];
+        }
+    };
+
+    // full comparison of one query against this lane's 4 subjects; qw = the whole record
+    auto full_compare = [&](const uint32_t(&qw)[RS], uint32_t q) {
+        const uint32_t U = ~qw[BS];
+        uint32_t d[4];
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const uint4 v = s[p * W + w];
+                const uint32_t qv = qw[qslot(P, W, p, w)];
+                m0 = p ? or_xor(m0, v.x, qv) : (v.x ^ qv);
+                m1 = p ? or_xor(m1, v.y, qv) : (v.y ^ qv);
+                m2 = p ? or_xor(m2, v.z, qv) : (v.z ^ qv);
+                m3 = p ? or_xor(m3, v.w, qv) : (v.w ^ qv);
+            }
+            d[0] = (w ? d[0] : 0u) + __builtin_popcount(m0);
+            d[1] = (w ? d[1] : 0u) + __builtin_popcount(m1);
+            d[2] = (w ? d[2] : 0u) + __builtin_popcount(m2);
+            d[3] = (w ? d[3] : 0u) + __builtin_popcount(m3);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, q, subj0 + k, d[k]);
+    };
+    auto read_record = [&](const uint4 *rec, uint32_t(&qw)[RS], int from, int to) {
+#pragma unroll
+        for (int v = from; v < to; v++) {
+            const uint4 x = rec[v];
+            qw[4 * v + 0] = x.x;
+            qw[4 * v + 1] = x.y;
+            qw[4 * v + 2] = x.z;
+            qw[4 * v + 3] = x.w;
+        }
+    };
+
+    if (q0 < q1) {
+        fetch(q0);
+        commit(0, q0);
+    }
+    __syncthreads();
+    int buf = 0;
+    bool filter_on = a.use_filter != 0;
+    uint32_t chunk_no = 0;
+    for (uint32_t qc = q0; qc < q1; qc += kChunk, buf ^= 1, chunk_no++) {
+        const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
+        const bool more = qc + kChunk < q1;
+        if (more) fetch(qc + kChunk);  // in flight while this chunk is computed
+        if (active) {
+            const uint4 *rec = &stage[buf][0];
+            const bool probe = a.use_filter && (filter_on || (chunk_no & 15u) == 0);
+            if (probe) {
+                uint32_t passes = 0;  // wave-uniform: queries of this chunk that needed the full comparison
+                for (uint32_t i = 0; i < nqc; i++, rec += RV) {
+                    uint32_t qw[RS];
+                    read_record(rec, qw, 0, HV);  // fast path: filter-plane words + bound slot only
+                    // lower bound on the filter plane, folded over the words
+                    uint32_t m0 = s[FP * W].x ^ qw[0], m1 = s[FP * W].y ^ qw[0];
+                    uint32_t m2 = s[FP * W].z ^ qw[0], m3 = s[FP * W].w ^ qw[0];
+#pragma unroll
+                    for (int w = 1; w < W; w++) {
+                        m0 = or_xor(m0, s[FP * W + w].x, qw[w]);
+                        m1 = or_xor(m1, s[FP * W + w].y, qw[w]);
+                        m2 = or_xor(m2, s[FP * W + w].z, qw[w]);
+                        m3 = or_xor(m3, s[FP * W + w].w, qw[w]);
+                    }
+                    const uint32_t nu = qw[BS];
+                    const uint32_t t0 = __builtin_popcount(m0) + nu, t1 = __builtin_popcount(m1) + nu;
+                    const uint32_t t2 = __builtin_popcount(m2) + nu, t3 = __builtin_popcount(m3) + nu;
+                    const uint32_t any = or3(t0, t1, t2) | t3;  // sign bit set <=> some lower bound <= bound
+                    if (__ballot((int32_t)any < 0) != 0ull) {  // wave-uniform branch
+                        passes++;
+                        read_record(rec, qw, HV, RV);
+                        full_compare(qw, qc + i);
+                    }
+                }
+                filter_on = passes * 4u <= nqc;
+            } else {
+#pragma unroll 2
+                for (uint32_t i = 0; i < nqc; i++, rec += RV) {
+                    uint32_t qw[RS];
+                    read_record(rec, qw, 0, RV);
+                    full_compare(qw, qc + i);
+                }
+            }
+        }
+        if (more) commit(buf ^ 1, qc + kChunk);
+        __syncthreads();
     }
 }
 
@@ -163,7 +293,7 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(const uint4 *__restri
     const uint32_t wg_tile = blockIdx.x % a.n_wg_tiles;
     const uint32_t qblock = blockIdx.x / a.n_wg_tiles;
     const uint32_t tile = a.tile_begin + wg_tile * kWgWaves + wave;
-    if (tile >= a.tile_end) return;
+    if (tile >= a.tile_end) return;  // no barrier in this kernel
     const uint4 *t = planes + (size_t)tile * ((size_t)P * W * 64) + lane;
     const uint32_t subj0 = tile * kWaveTile + lane * 4u;
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
@@ -176,7 +306,7 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(const uint4 *__restri
             uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
             for (uint32_t p = 0; p < P; p++) {
                 const uint4 v = t[(p * W + w) * 64];
-                const uint32_t qv = qr[p * W + w];
+                const uint32_t qv = qr[qslot((int)P, (int)W, (int)p, (int)w)];
                 m0 = or_xor(m0, v.x, qv);
                 m1 = or_xor(m1, v.y, qv);
                 m2 = or_xor(m2, v.z, qv);
@@ -208,7 +338,7 @@ __global__ __launch_bounds__(256) void distances_kernel(const uint4 *__restrict_
         uint4 m = make_uint4(0, 0, 0, 0);
         for (uint32_t p = 0; p < P; p++) {
             const uint4 v = t[(p * W + w) * 64];
-            const uint32_t qv = qrec[p * W + w];
+            const uint32_t qv = qrec[qslot((int)P, (int)W, (int)p, (int)w)];
             m.x = or_xor(m.x, v.x, qv);
             m.y = or_xor(m.y, v.y, qv);
             m.z = or_xor(m.z, v.z, qv);
@@ -228,7 +358,7 @@ __global__ __launch_bounds__(256) void distances_kernel(const uint4 *__restrict_
 // slice of plane p (low half = word 2h, high half = word 2h+1).  A wave packs 64 consecutive rows,
 // parks row i's words in lane i, then stores each (plane, word) as one coalesced 256-byte row.
 //   mode 0: subject tile layout   out[((tile*P + p)*W + w)*256 + (row & 255)]
-//   mode 1: query record layout   out[row*QS + p*W + w]
+//   mode 1: query record layout   out[row*QS + qslot(p, w)]
 // `first` = absolute index of codes row 0 (appends start mid-tile); rows are absolute indices.
 // ---------------------------------------------------------------------------------------------
 template <int P>
@@ -272,7 +402,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *codes, ui
                         const uint64_t tile = my_row >> 8;
                         out[((tile * P + p) * W + w) * 256 + (my_row & 255)] = v;
                     } else {
-                        out[my_row * QS + p * W + w] = v;
+                        out[my_row * QS + qslot(P, (int)W, p, (int)w)] = v;
                     }
                 }
             }
