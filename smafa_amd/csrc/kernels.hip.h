@@ -43,6 +43,13 @@ constexpr int kWaveTile = 256;  // subjects per wave tile
 constexpr int kWgWaves = 4;     // waves per workgroup
 constexpr int kWgTile = kWaveTile * kWgWaves;
 constexpr int kChunk = 64;      // queries staged in LDS at a time
+#ifndef SMAFA_GROUP
+#define SMAFA_GROUP 1  // queries per fast-path step (one compare + branch per group); 1 measured best, profiles/r01_variant_matrix.txt
+#endif
+#ifndef SMAFA_MIN_WAVES
+#define SMAFA_MIN_WAVES 6  // __launch_bounds__ second argument: waves per SIMD the register budget must allow
+#endif
+constexpr int kGroup = SMAFA_GROUP;
 
 __host__ __device__ constexpr int round_up4(int x) { return (x + 3) & ~3; }
 // query record stride in u32 words: the plane words plus the bound slot, rounded up to whole uint4s
@@ -135,7 +142,7 @@ __device__ __forceinline__ uint32_t comp(const uint4 &v) {
 // queries) the wave switches to the plain full comparison and re-probes every 16th chunk.
 // ---------------------------------------------------------------------------------------------
 template <int P, int W>
-__global__ __launch_bounds__(256) void scan_kernel(const uint4 *__restrict__ planes,
+__global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 *__restrict__ planes,
                                                    const uint32_t *__restrict__ qrec, ScanArgs a) {
     constexpr int RS = qrec_stride(P, W);  // words per record
     constexpr int RV = RS / 4;             // uint4 per record
@@ -189,6 +196,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint4 *__restrict__ pla
         for (int v = 0; v < NV; v++) {
             const uint32_t idx = tid + v * 256;
             if (idx < nqc * RV) stage[buf][idx] = pre[v];
+            else if (idx < (nqc + kGroup - 1) / kGroup * kGroup * RV)
+                stage[buf][idx] = make_uint4(0, 0, 0, 0);  // never-pass padding up to a whole group
         }
     };
 
@@ -245,27 +254,64 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint4 *__restrict__ pla
             const bool probe = a.use_filter && (filter_on || (chunk_no & 15u) == 0);
             if (probe) {
                 uint32_t passes = 0;  // wave-uniform: queries of this chunk that needed the full comparison
-                for (uint32_t i = 0; i < nqc; i++, rec += RV) {
-                    uint32_t qw[RS];
-                    read_record(rec, qw, 0, HV);  // fast path: filter-plane words + bound slot only
-                    // lower bound on the filter plane, folded over the words
-                    uint32_t m0 = s[FP * W].x ^ qw[0], m1 = s[FP * W].y ^ qw[0];
-                    uint32_t m2 = s[FP * W].z ^ qw[0], m3 = s[FP * W].w ^ qw[0];
+                // kGroup queries per step: their sign words are OR-ed into one, so the common case costs one
+                // compare + one branch per group.  Records past nqc are zero (bound slot 0 => never pass).
+                for (uint32_t i = 0; i < nqc; i += kGroup, rec += kGroup * RV) {
+                    uint32_t head[kGroup][4 * HV];
+                    uint32_t any[kGroup];
 #pragma unroll
-                    for (int w = 1; w < W; w++) {
-                        m0 = or_xor(m0, s[FP * W + w].x, qw[w]);
-                        m1 = or_xor(m1, s[FP * W + w].y, qw[w]);
-                        m2 = or_xor(m2, s[FP * W + w].z, qw[w]);
-                        m3 = or_xor(m3, s[FP * W + w].w, qw[w]);
+                    for (int j = 0; j < kGroup; j++) {
+#pragma unroll
+                        for (int v = 0; v < HV; v++) {
+                            const uint4 x = rec[j * RV + v];
+                            head[j][4 * v + 0] = x.x;
+                            head[j][4 * v + 1] = x.y;
+                            head[j][4 * v + 2] = x.z;
+                            head[j][4 * v + 3] = x.w;
+                        }
                     }
-                    const uint32_t nu = qw[BS];
-                    const uint32_t t0 = __builtin_popcount(m0) + nu, t1 = __builtin_popcount(m1) + nu;
-                    const uint32_t t2 = __builtin_popcount(m2) + nu, t3 = __builtin_popcount(m3) + nu;
-                    const uint32_t any = or3(t0, t1, t2) | t3;  // sign bit set <=> some lower bound <= bound
-                    if (__ballot((int32_t)any < 0) != 0ull) {  // wave-uniform branch
-                        passes++;
-                        read_record(rec, qw, HV, RV);
-                        full_compare(qw, qc + i);
+#pragma unroll
+                    for (int j = 0; j < kGroup; j++) {
+                        // lower bound on the filter plane, folded over the words
+                        uint32_t m0 = s[FP * W].x ^ head[j][0], m1 = s[FP * W].y ^ head[j][0];
+                        uint32_t m2 = s[FP * W].z ^ head[j][0], m3 = s[FP * W].w ^ head[j][0];
+#pragma unroll
+                        for (int w = 1; w < W; w++) {
+                            m0 = or_xor(m0, s[FP * W + w].x, head[j][w]);
+                            m1 = or_xor(m1, s[FP * W + w].y, head[j][w]);
+                            m2 = or_xor(m2, s[FP * W + w].z, head[j][w]);
+                            m3 = or_xor(m3, s[FP * W + w].w, head[j][w]);
+                        }
+                        const uint32_t nu = head[j][BS];
+                        const uint32_t t0 = __builtin_popcount(m0) + nu, t1 = __builtin_popcount(m1) + nu;
+                        const uint32_t t2 = __builtin_popcount(m2) + nu, t3 = __builtin_popcount(m3) + nu;
+                        any[j] = j ? or3(or3(t0, t1, t2), t3, any[j - 1]) : (or3(t0, t1, t2) | t3);  // running OR
+                    }
+                    if (__ballot((int32_t)any[kGroup - 1] < 0) != 0ull) {  // wave-uniform, rare
+#pragma unroll
+                        for (int j = 0; j < kGroup; j++) {
+                            // any[j] is cumulative; query j itself passed iff its own bits did: recompute cheaply
+                            uint32_t qw[RS];
+#pragma unroll
+                            for (int v = 0; v < 4 * HV; v++) qw[v] = head[j][v];
+                            uint32_t m0 = s[FP * W].x ^ qw[0], m1 = s[FP * W].y ^ qw[0];
+                            uint32_t m2 = s[FP * W].z ^ qw[0], m3 = s[FP * W].w ^ qw[0];
+#pragma unroll
+                            for (int w = 1; w < W; w++) {
+                                m0 = or_xor(m0, s[FP * W + w].x, qw[w]);
+                                m1 = or_xor(m1, s[FP * W + w].y, qw[w]);
+                                m2 = or_xor(m2, s[FP * W + w].z, qw[w]);
+                                m3 = or_xor(m3, s[FP * W + w].w, qw[w]);
+                            }
+                            const uint32_t nu = qw[BS];
+                            const uint32_t own = or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
+                                                     __builtin_popcount(m2) + nu) | (__builtin_popcount(m3) + nu);
+                            if (i + j < nqc && __ballot((int32_t)own < 0) != 0ull) {
+                                passes++;
+                                read_record(rec + j * RV, qw, HV, RV);
+                                full_compare(qw, qc + i + j);
+                            }
+                        }
                     }
                 }
                 filter_on = passes * 4u <= nqc;
