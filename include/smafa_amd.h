@@ -151,6 +151,10 @@ int smafa_select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries
  * Version 3 is this build's extension container for amino-acid stores (alphabet byte + raw code rows). */
 int smafa_dbfile_write(const char *path, int alphabet, const uint8_t *codes, uint64_t n, uint32_t seq_len);
 int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t *n, uint32_t *seq_len);
+/* Read a FASTA/FASTQ(+gzip) file of equal-length records into malloc'd code rows (free with smafa_free) —
+ * parse_fastx_file + from_bytes per record (src/lib.rs:221,235).  Fails like the reference on a byte outside
+ * the alphabet (message of src/lib.rs:38-41); records of unequal length fail with SMAFA_ERR_PANIC. */
+int smafa_fastx_load(const char *path, int alphabet, uint8_t **codes, uint64_t *n, uint32_t *seq_len);
 void smafa_free(void *p);
 
 /* ------------------------------------------- drivers: the crate's pub fns */

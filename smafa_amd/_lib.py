@@ -26,7 +26,7 @@ EXPORTS = [
     "smafa_db_create", "smafa_db_append", "smafa_db_info", "smafa_db_set_stream", "smafa_db_destroy",
     "smafa_scan_hits", "smafa_distances", "smafa_qset_create", "smafa_qset_destroy", "smafa_scan_launch",
     "smafa_sync", "smafa_last_scan_ms", "smafa_set_query_block", "smafa_select_rows",
-    "smafa_dbfile_write", "smafa_dbfile_read", "smafa_free",
+    "smafa_dbfile_write", "smafa_dbfile_read", "smafa_fastx_load", "smafa_free",
     "smafa_makedb", "smafa_query", "smafa_cluster", "smafa_count",
 ]
 
@@ -90,6 +90,7 @@ def lib() -> C.CDLL:
                                     C.c_uint32, vp, C.c_uint64, u64p]
     l.smafa_dbfile_write.argtypes = [C.c_char_p, C.c_int, vp, C.c_uint64, C.c_uint32]
     l.smafa_dbfile_read.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(vp), u64p, u32p]
+    l.smafa_fastx_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), u64p, u32p]
     l.smafa_free.argtypes = [vp]
     l.smafa_free.restype = None
     l.smafa_makedb.argtypes = [C.c_char_p, C.c_char_p, C.c_int]

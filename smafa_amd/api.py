@@ -189,6 +189,18 @@ def read_db(path: str) -> tuple[int, np.ndarray]:
     return alphabet.value, arr.reshape(n.value, L.value)
 
 
+def load_fastx(path: str, alphabet: int = ALPHABET_NT) -> np.ndarray:
+    """FASTA/FASTQ(+gzip) of equal-length records -> code rows (needletail + from_bytes, src/lib.rs:221,235)."""
+    ptr, n, L = C.c_void_p(), C.c_uint64(0), C.c_uint32(0)
+    check(lib().smafa_fastx_load(os.fsencode(path), alphabet, C.byref(ptr), C.byref(n), C.byref(L)))
+    try:
+        size = n.value * L.value
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(max(size, 1),))[:size].copy()
+    finally:
+        lib().smafa_free(ptr)
+    return arr.reshape(n.value, L.value)
+
+
 def write_db(path: str, codes: np.ndarray, alphabet: int = ALPHABET_NT) -> None:
     c = np.ascontiguousarray(codes, dtype=np.uint8)
     check(lib().smafa_dbfile_write(os.fsencode(path), alphabet, c.ctypes.data, c.shape[0], c.shape[1]))

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -134,6 +135,40 @@ class RowSet {
 using namespace smafa;
 
 extern "C" {
+
+// ---------------------------------------------------------------------------------- fastx_load
+int smafa_fastx_load(const char *path, int alphabet, uint8_t **codes_out, uint64_t *n_out, uint32_t *seq_len) {
+    if (!path || !codes_out || !n_out || !seq_len) return set_error(SMAFA_ERR_INVALID, "smafa_fastx_load: NULL argument");
+    if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
+        return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
+    *codes_out = nullptr;
+    *n_out = 0;
+    *seq_len = 0;
+    FastxReader reader;
+    int rc = reader.open(path);
+    if (rc) return rc;
+    std::vector<uint8_t> codes;
+    uint64_t n = 0;
+    size_t L = 0;
+    FastxRecord rec;
+    while ((rc = reader.next(rec)) == 1) {
+        int erc = encode_record(alphabet, rec, codes);
+        if (erc) return erc;
+        if (n == 0) L = rec.seq_len;
+        else if (rec.seq_len != L)
+            return set_error(SMAFA_ERR_PANIC, "Cannot compute distances between seq of length %zu and windows of lengths %zu",
+                             rec.seq_len, L);
+        n++;
+    }
+    if (rc < 0) return rc;
+    uint8_t *out = (uint8_t *)malloc(codes.empty() ? 1 : codes.size());
+    if (!out) return set_error(SMAFA_ERR_IO, "out of memory");
+    if (!codes.empty()) memcpy(out, codes.data(), codes.size());
+    *codes_out = out;
+    *n_out = n;
+    *seq_len = (uint32_t)L;
+    return SMAFA_OK;
+}
 
 // ------------------------------------------------------------------------------------- makedb
 int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet) {
