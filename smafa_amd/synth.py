@@ -58,3 +58,41 @@ def queries(subject_codes: np.ndarray, q: int, alphabet: int = 1, seed: int = 3,
         # a column holding a symbol outside the generator's set (an N) is replaced by a letter: still a change
         out[i, pos] = np.where(np.isin(cur, lc) & ok, new, lc[shift[i, pos] % len(lc)])
     return out, rows, subs
+
+
+def cluster_records(n_roots: int, members: int, seq_len: int = 60, alphabet: int = 1, seed: int = 4,
+                    max_subs: int = 4) -> np.ndarray:
+    """SURVEY.md §8(d) cluster workload: n_roots uniform roots x `members` members, each member = its root
+    with s in 0..max_subs substitutions, Fisher-Yates shuffled.  Returns code rows."""
+    rng = np.random.default_rng(seed)
+    lc = letter_codes(alphabet)
+    roots = lc[rng.integers(0, len(lc), size=(n_roots, seq_len), dtype=np.uint8)]
+    recs = np.repeat(roots, members, axis=0)
+    n = len(recs)
+    subs = rng.integers(0, max_subs + 1, size=n)
+    for s in range(1, max_subs + 1):  # s-th substitution for every record that has at least s
+        rows = np.nonzero(subs >= s)[0]
+        cols = rng.integers(0, seq_len, size=len(rows))
+        recs[rows, cols] = lc[rng.integers(0, len(lc), size=len(rows))]
+    rng.shuffle(recs, axis=0)
+    return recs
+
+
+def write_fasta(path: str, code_rows: np.ndarray, alphabet: int = 1, prefix: str = "r") -> None:
+    """code rows -> single-line FASTA (vectorised; fine for millions of rows)"""
+    if alphabet == 1:
+        letters = np.array([ord("A") + i for i in range(26)] + [ord("*"), ord("-")], dtype=np.uint8)
+    else:
+        letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    n, L = code_rows.shape
+    ascii_rows = letters[code_rows]
+    with open(path, "wb") as f:
+        step = 200_000
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            parts = []
+            for i in range(lo, hi):
+                parts.append(b">%s%d\n" % (prefix.encode(), i))
+                parts.append(ascii_rows[i].tobytes())
+                parts.append(b"\n")
+            f.write(b"".join(parts))
