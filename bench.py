@@ -44,6 +44,7 @@ def main() -> None:
     ap.add_argument("--max-div", type=int, default=5)
     ap.add_argument("--query-block", type=int, default=0, help="queries per workgroup pass (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="skip the one-query-per-pass leg (clean rocprof stats)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -151,7 +152,7 @@ def main() -> None:
     # ---- stream mode: ONE query per pass — the HBM-bound form of the same kernel (north_star's literal
     #      "broadcast each query against all subjects"); reported beside the batched roofline
     stream_info = None
-    if rank == 0:
+    if rank == 0 and not args.no_stream:
         one = smafa_amd.QuerySet(store, my_q[:1])
         for _ in range(3):
             store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
@@ -200,7 +201,16 @@ def main() -> None:
         pairs_per_launch = Q * N
         alg_bytes = pairs_per_launch * L  # B_s = L x 8 bits / 8 = 60 B per (query, subject)
         achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
-        ops_per_pair = (info.planes * info.words_per_plane + info.words_per_plane + 0.75)
+        filt = os.environ.get("SMAFA_FILTER", "1") != "0"
+        W_, P_ = info.words_per_plane, info.planes
+        # VALU wave-instructions per (query, subject) pair = lane-ops per pair.  Prefilter fast path, per lane and
+        # query: 4 subjects x (W xor/bitop3 + 1 popcount) + or3 + or + compare + LDS address = 4(W+1) + 4.
+        # Full comparison: 4 subjects x (P*W xor/bitop3 + W popcounts) + 4 compares.
+        ops_per_pair = (W_ + 2.0) if filt else (P_ * W_ + W_ + 1.0)
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc_path) and (N, L, Q, D, args.alphabet) == (10_000_000, 60, 10_000, 5, "aa"):
+            traffic = json.load(open(pmc_path))["batched_launch"]["hbm_bytes"]  # measured per launch, same workload
         out = {
             "metric": "query seqs/sec (DB residues/sec in `residues_per_s`) vs HBM roofline, %dM x %d%s DB, d<=%d"
                       % (N // 1_000_000, L, args.alphabet, D),
@@ -233,19 +243,25 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + "
+                                  "WRITE_SIZE, bytes per launch)" if traffic else None,
                 "kernel_ms_avg": kernel_ms_avg,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "algorithmic bytes = queries x subjects x %d B (SURVEY 8d). The kernel keeps a 1024-subject "
                         "tile in registers and walks a whole query block over it, so the store is streamed from HBM "
-                        "once per query block, not once per query: frac > 1 is register-level reuse, NOT HBM "
-                        "efficiency. The real ceiling of this kernel is VALU issue (see `valu`); the HBM-bound form "
-                        "(one query per pass) is in `stream`." % L,
+                        "once per query block, not once per query (see `traffic`): frac > 1 is register-level reuse "
+                        "plus the exact lower-bound prefilter, NOT HBM efficiency. The real ceiling of this kernel "
+                        "is VALU issue (see `valu`); the HBM-bound form (one query per pass) is in `stream`." % L,
                 "valu": {
+                    "prefilter": filt,
                     "lane_ops_per_pair": ops_per_pair,
                     "achieved_lane_ops": pairs_per_launch * ops_per_pair / (kernel_ms_avg * 1e-3),
                     "peak_lane_ops": VALU_PEAK_LANE_OPS,
                     "frac": pairs_per_launch * ops_per_pair / (kernel_ms_avg * 1e-3) / VALU_PEAK_LANE_OPS,
+                    "note": "peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; measured issue rates on this chip "
+                            "(profiles/r01_ubench_valu*.txt): all-VGPR xor/bitop3/add ~60e12, v_bcnt/v_cmp/v_min and "
+                            "any op with an SGPR source ~37e12 lane-ops/s",
                 },
                 "stored_bytes_per_subject": int(info.bytes_per_subject),
             },
