@@ -174,6 +174,18 @@ def main() -> None:
         }
         one.close()
 
+    # ---- host-buffer API (PCIe-inclusive): queries uploaded + packed, rows copied back and ordered on the host
+    host_api = None
+    if rank == 0 and world == 1 and not args.no_stream:
+        store.scan(my_q[:64], max_divergence=D)
+        reps = 3
+        tq = time.perf_counter()
+        for _ in range(reps):
+            rows_h = store.scan(my_q, max_divergence=D)
+        dt = (time.perf_counter() - tq) / reps
+        host_api = {"queries_per_s": Q / dt, "ms_per_batch": dt * 1e3, "rows": int(len(rows_h)),
+                    "note": "smafa_scan_hits: host code bytes in, ordered rows out (upload, pack, scan, copy back, sort)"}
+
     # ---- CPU baseline: the oracle's port of the reference's per-query loop, one thread, bounded sample
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -266,6 +278,7 @@ def main() -> None:
                 "stored_bytes_per_subject": int(info.bytes_per_subject),
             },
             "stream": stream_info,
+            "host_api": host_api,
             "cpu_baseline": cpu,
             "setup_s": {"generate": t_gen, "pack_upload": t_up},
         }
