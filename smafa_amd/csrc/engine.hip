@@ -1,6 +1,9 @@
 // engine.hip — device half of the C ABI (include/smafa_amd.h): HBM-resident subject store, packed
-// query sets, scan launches, hit collection.  Host-only entry points (FASTX, DB file, selection,
-// drivers) live in host/*.cpp.  No CPU fallback anywhere: without a HIP device every call here fails.
+// query sets, scan launches, row collection and ordering.  Host-only entry points (FASTX, DB file,
+// selection, drivers) live in host/*.cpp.  No CPU fallback anywhere: without a HIP device every call
+// here fails.
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -19,9 +22,38 @@ namespace smafa {
 
 static int planes_for(int alphabet) { return alphabet == SMAFA_ALPHABET_AA ? 5 : 3; }
 
+// grow-only device buffer (scratch that is reused across calls: hipMalloc/hipFree cost far more than a scan)
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SMAFA_OK;
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max<size_t>(bytes, 4096);
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return SMAFA_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 }  // namespace smafa
 
 using namespace smafa;
+
+struct smafa_qset {
+    smafa_db *db = nullptr;
+    uint64_t nq = 0;
+    DevBuf qrec, thr, cnt;  // packed records, per-query bounds, per-query distance histograms (k >= 2 only)
+};
 
 struct smafa_db {
     int device = 0;
@@ -37,19 +69,13 @@ struct smafa_db {
     uint32_t qb_override = 0;
     bool use_filter = true;  // exact lower-bound prefilter in the scan kernel (SMAFA_FILTER=0 disables)
     int n_cu = 256;
-    // scratch of the host-buffer scan API, kept across calls
-    smafa_hit *d_hits = nullptr;
-    uint64_t hits_cap = 0;
-    unsigned long long *d_count = nullptr;
+    // scratch of the host-buffer API, kept across calls
+    DevBuf upload;            // staging for code rows on their way to the pack kernel
+    DevBuf hits, count;       // rows and their counter
+    DevBuf keys_a, keys_b, sort_tmp;
+    smafa_qset scratch_q;     // query set of smafa_scan_hits / smafa_distances
     size_t tile_words() const { return (size_t)P * W * kWaveTile; }
-};
-
-struct smafa_qset {
-    smafa_db *db = nullptr;
-    uint64_t nq = 0;
-    uint32_t *d_qrec = nullptr;
-    uint32_t *d_thr = nullptr;
-    uint32_t *d_cnt = nullptr;  // lazily allocated: nq * (L+1)
+    uint64_t hits_cap() const { return hits.cap / sizeof(smafa_hit); }
 };
 
 namespace smafa {
@@ -62,24 +88,22 @@ static int use_device(const smafa_db *db) {
 // upload code rows and pack them with the ballot kernel
 static int pack_rows(smafa_db *db, const uint8_t *codes, uint64_t first, uint64_t n, uint32_t *d_out, int mode) {
     if (n == 0) return SMAFA_OK;
-    uint8_t *d_codes = nullptr;
     const size_t bytes = (size_t)n * db->L;
-    HIP_TRY(hipMalloc(&d_codes, bytes));
-    hipError_t e = hipMemcpyAsync(d_codes, codes, bytes, hipMemcpyHostToDevice, db->stream);
-    if (e == hipSuccess) {
-        const uint64_t groups = (first + n + 63) / 64 - first / 64;
-        const uint32_t blocks = (uint32_t)((groups + kWgWaves - 1) / kWgWaves);
-        if (db->P == 5)
-            hipLaunchKernelGGL(pack_rows_kernel<5>, dim3(blocks), dim3(256), 0, db->stream, d_codes, first, n, db->L,
-                               db->W, d_out, mode, db->QS);
-        else
-            hipLaunchKernelGGL(pack_rows_kernel<3>, dim3(blocks), dim3(256), 0, db->stream, d_codes, first, n, db->L,
-                               db->W, d_out, mode, db->QS);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
-    hipFree(d_codes);
-    if (e != hipSuccess) return set_error(SMAFA_ERR_DEVICE, "packing rows failed: %s", hipGetErrorString(e));
+    int rc = db->upload.ensure(bytes);
+    if (rc) return rc;
+    uint8_t *d_codes = db->upload.as<uint8_t>();
+    HIP_TRY(hipMemcpyAsync(d_codes, codes, bytes, hipMemcpyHostToDevice, db->stream));
+    const uint64_t groups = (first + n + 63) / 64 - first / 64;
+    const uint32_t blocks = (uint32_t)((groups + kWgWaves - 1) / kWgWaves);
+    if (db->P == 5)
+        hipLaunchKernelGGL(pack_rows_kernel<5>, dim3(blocks), dim3(256), 0, db->stream, d_codes, first, n, db->L, db->W,
+                           d_out, mode, db->QS);
+    else
+        hipLaunchKernelGGL(pack_rows_kernel<3>, dim3(blocks), dim3(256), 0, db->stream, d_codes, first, n, db->L, db->W,
+                           d_out, mode, db->QS);
+    HIP_TRY(hipGetLastError());
+    // the caller's host buffer is borrowed for the call only, and `upload` is reused by the next call
+    HIP_TRY(hipStreamSynchronize(db->stream));
     return SMAFA_OK;
 }
 
@@ -113,17 +137,34 @@ static int reserve_tiles(smafa_db *db, uint64_t need_tiles) {
     return SMAFA_OK;
 }
 
+// fill a query set (its buffers grow as needed) from host code rows
+static int qset_fill(smafa_qset *qs, smafa_db *db, const uint8_t *query_codes, uint64_t n_queries) {
+    qs->db = db;
+    qs->nq = n_queries;
+    const uint64_t padded = std::max<uint64_t>((n_queries + 63) / 64 * 64, 64);
+    int rc = qs->qrec.ensure(padded * db->QS * sizeof(uint32_t));
+    if (!rc) rc = qs->thr.ensure(padded * sizeof(uint32_t));
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(qs->qrec.p, 0, padded * db->QS * sizeof(uint32_t), db->stream));
+    return pack_rows(db, query_codes, 0, n_queries, qs->qrec.as<uint32_t>(), 1);
+}
+
 template <int P, int W>
 static void launch_scan_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
-    hipLaunchKernelGGL((scan_kernel<P, W>), dim3(grid), dim3(256), 0, db->stream,
-                       reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
+    // the seed pass of the running-minimum mode (no append) has its own instantiation
+    if (a.hits == nullptr && a.k_tight == 1)
+        hipLaunchKernelGGL((scan_kernel<P, W, true>), dim3(grid), dim3(256), 0, db->stream,
+                           reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
+    else
+        hipLaunchKernelGGL((scan_kernel<P, W, false>), dim3(grid), dim3(256), 0, db->stream,
+                           reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
 }
 
 static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
-#define SMAFA_CASE(P_, W_)                                  \
-    if (db->P == P_ && db->W == W_) {                       \
-        launch_scan_t<P_, W_>(db, d_qrec, a, grid);         \
-        return;                                             \
+#define SMAFA_CASE(P_, W_)                          \
+    if (db->P == P_ && db->W == W_) {               \
+        launch_scan_t<P_, W_>(db, d_qrec, a, grid); \
+        return;                                     \
     }
     SMAFA_CASE(3, 1) SMAFA_CASE(3, 2) SMAFA_CASE(3, 3) SMAFA_CASE(3, 4)
     SMAFA_CASE(5, 1) SMAFA_CASE(5, 2) SMAFA_CASE(5, 3) SMAFA_CASE(5, 4)
@@ -136,7 +177,7 @@ static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanAr
 // VALU issue, not HBM), small enough that the grid has many more workgroups than the chip has slots.
 static uint32_t choose_query_block(const smafa_db *db, uint32_t n_wg_tiles, uint32_t nq) {
     if (db->qb_override) return std::min<uint32_t>(std::max<uint32_t>(db->qb_override, 1u), std::max(nq, 1u));
-    const uint32_t slots = (uint32_t)db->n_cu * 8u;  // 8 workgroups of 4 waves per CU at <= 64 VGPRs
+    const uint32_t slots = (uint32_t)db->n_cu * 6u;  // 6 workgroups of 4 waves per CU at the kernel's register budget
     const uint32_t want_items = slots * 16u;
     uint32_t nqb = (want_items + n_wg_tiles - 1) / n_wg_tiles;
     const uint32_t max_nqb = std::max(1u, nq / 256u);
@@ -157,8 +198,8 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     a.q_begin = q_begin;
     a.q_end = q_end;
     a.qb_size = choose_query_block(db, a.n_wg_tiles, q_end - q_begin);
-    a.thr = qs->d_thr;
-    a.cnt = qs->d_cnt;
+    a.thr = qs->thr.as<uint32_t>();
+    a.cnt = qs->cnt.as<uint32_t>();
     a.cnt_stride = db->L + 1;
     a.k_tight = k_tight;
     a.use_filter = db->use_filter ? 1u : 0u;
@@ -169,7 +210,7 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     const uint64_t grid = n_qblocks * a.n_wg_tiles;
     if (grid > 0x7fffffffull)
         return set_error(SMAFA_ERR_INVALID, "scan grid too large (%llu workgroups)", (unsigned long long)grid);
-    launch_scan(db, qs->d_qrec, a, (uint32_t)grid);
+    launch_scan(db, qs->qrec.as<uint32_t>(), a, (uint32_t)grid);
     HIP_TRY(hipGetLastError());
     db->last_launches++;
     return SMAFA_OK;
@@ -189,14 +230,15 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     db->timed = false;
     if (nq == 0 || db->n == 0) return SMAFA_OK;
     const uint32_t thr0 = std::min<uint32_t>(max_div, db->L);  // a distance never exceeds seq_len
-    hipLaunchKernelGGL(fill_u32_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream, qs->d_thr + q_begin, thr0,
-                       (uint64_t)nq);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream, qs->thr.as<uint32_t>() + q_begin,
+                       thr0, (uint64_t)nq);
     const size_t cnt_stride = db->L + 1;
     auto zero_cnt = [&]() -> int {
         if (k_tight < 2) return SMAFA_OK;
-        if (!qs->d_cnt) HIP_TRY(hipMalloc(&qs->d_cnt, qs->nq * cnt_stride * sizeof(uint32_t)));
-        HIP_TRY(hipMemsetAsync(qs->d_cnt + (size_t)q_begin * cnt_stride, 0, (size_t)nq * cnt_stride * sizeof(uint32_t),
-                               db->stream));
+        int rc = qs->cnt.ensure(std::max<uint64_t>(qs->nq, 64) * cnt_stride * sizeof(uint32_t));
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(qs->cnt.as<uint32_t>() + (size_t)q_begin * cnt_stride, 0,
+                               (size_t)nq * cnt_stride * sizeof(uint32_t), db->stream));
         return SMAFA_OK;
     };
     const uint32_t n_tiles = (uint32_t)((db->n + kWaveTile - 1) / kWaveTile);
@@ -206,7 +248,9 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
         rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, d_hits, cap, d_count);
     } else {
         rc = zero_cnt();
-        const uint32_t seed_tiles = std::min<uint32_t>(kWgWaves, n_tiles);
+        // seed: k = 1 reduces each wave's minimum before its single atomicMin, so a whole workgroup tile is
+        // cheap; the k >= 2 seed counts every pair in its histogram, so keep it to one wave tile
+        const uint32_t seed_tiles = std::min<uint32_t>(k_tight == 1 ? kWgWaves : 1, n_tiles);
         if (!rc) rc = launch_tiles(db, qs, q_begin, q_end, 0, seed_tiles, k_tight, nullptr, 0, d_count);
         if (!rc) rc = zero_cnt();  // the seed's subjects are counted again below
         uint32_t begin = 0, len = kWgWaves;
@@ -229,21 +273,60 @@ static bool hit_less(const smafa_hit &x, const smafa_hit &y) {
     return x.subject < y.subject;
 }
 
-static int ensure_scratch(smafa_db *db, uint64_t rows) {
-    if (!db->d_count) HIP_TRY(hipMalloc(&db->d_count, sizeof(unsigned long long)));
-    if (rows > db->hits_cap) {
-        if (db->d_hits) HIP_TRY(hipFree(db->d_hits));
-        db->d_hits = nullptr;
-        db->hits_cap = 0;
-        HIP_TRY(hipMalloc(&db->d_hits, rows * sizeof(smafa_hit)));
-        db->hits_cap = rows;
-    }
+// ---- ordering rows on the device: (query, dist, subject) packed into one 64-bit radix key -------------
+__global__ void rows_to_keys_kernel(const smafa_hit *rows, uint64_t n, uint32_t q_begin, uint32_t dist_bits,
+                                    unsigned long long *keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const smafa_hit h = rows[i];
+    keys[i] = ((unsigned long long)(h.query - q_begin) << (32 + dist_bits)) | ((unsigned long long)h.dist << 32) | h.subject;
+}
+
+__global__ void keys_to_rows_kernel(const unsigned long long *keys, uint64_t n, uint32_t q_begin, uint32_t dist_bits,
+                                    smafa_hit *rows) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    smafa_hit h;
+    h.subject = (uint32_t)k;
+    h.dist = (uint32_t)(k >> 32) & ((1u << dist_bits) - 1u);
+    h.query = (uint32_t)(k >> (32 + dist_bits)) + q_begin;
+    rows[i] = h;
+}
+
+// Sort db->hits[0..count) by (query, dist, subject) in place with a device radix sort; returns false (and leaves
+// the rows untouched) when the key does not fit 64 bits — the caller then orders them on the host.
+static int sort_rows_on_device(smafa_db *db, uint64_t count, uint32_t q_begin, uint32_t q_end, bool *sorted) {
+    *sorted = false;
+    uint32_t dist_bits = 1;
+    while ((1u << dist_bits) <= db->L) dist_bits++;
+    uint32_t q_bits = 1;
+    while (q_bits < 32 && (1ull << q_bits) < (uint64_t)(q_end - q_begin)) q_bits++;
+    if (dist_bits + q_bits > 32 || count > 0x7fffffffull) return SMAFA_OK;
+    int rc = db->keys_a.ensure(count * sizeof(unsigned long long));
+    if (!rc) rc = db->keys_b.ensure(count * sizeof(unsigned long long));
+    if (rc) return rc;
+    unsigned long long *ka = db->keys_a.as<unsigned long long>(), *kb = db->keys_b.as<unsigned long long>();
+    const uint32_t blocks = (uint32_t)((count + 255) / 256);
+    hipLaunchKernelGGL(rows_to_keys_kernel, dim3(blocks), dim3(256), 0, db->stream, db->hits.as<smafa_hit>(), count, q_begin,
+                       dist_bits, ka);
+    size_t tmp_bytes = 0;
+    const int end_bit = (int)(32 + dist_bits + q_bits);
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, ka, kb, (int)count, 0, end_bit, db->stream));
+    rc = db->sort_tmp.ensure(tmp_bytes);
+    if (rc) return rc;
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeys(db->sort_tmp.p, tmp_bytes, ka, kb, (int)count, 0, end_bit, db->stream));
+    hipLaunchKernelGGL(keys_to_rows_kernel, dim3(blocks), dim3(256), 0, db->stream, kb, count, q_begin, dist_bits,
+                       db->hits.as<smafa_hit>());
+    HIP_TRY(hipGetLastError());
+    *sorted = true;
     return SMAFA_OK;
 }
 
-// Collect all qualifying rows of queries [q_begin, q_end) into `out` (host, unordered).
-// First try the plain bound when there is one (rows within max_div are usually few); if they do not
-// fit, tighten to the k-th smallest distance; if that still does not fit, halve the query range.
+// Collect all qualifying rows of queries [q_begin, q_end) into `out` (host).  First the plain bound when there
+// is one (rows within max_div are usually few); if they do not fit, tighten to the k-th smallest distance; if
+// that still does not fit, halve the query range.  Ranges are visited in ascending query order and each is
+// ordered by (query, dist, subject) — on the device when it is big enough to matter — so `out` is ordered.
 static int collect_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t max_div,
                          uint32_t max_num_hits, std::vector<smafa_hit> &out) {
     const uint32_t k_tight = max_num_hits == SMAFA_NONE ? 0u : max_num_hits;
@@ -258,11 +341,12 @@ static int collect_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_
             if (!k_tight) break;
             k = k_tight;
         }
-        int rc = scan_range(db, qs, q_begin, q_end, max_div, k, db->d_hits, db->hits_cap, db->d_count);
+        int rc = scan_range(db, qs, q_begin, q_end, max_div, k, db->hits.as<smafa_hit>(), db->hits_cap(),
+                            db->count.as<unsigned long long>());
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(&count, db->d_count, sizeof count, hipMemcpyDeviceToHost, db->stream));
+        HIP_TRY(hipMemcpyAsync(&count, db->count.p, sizeof count, hipMemcpyDeviceToHost, db->stream));
         HIP_TRY(hipStreamSynchronize(db->stream));
-        done = count <= db->hits_cap;
+        done = count <= db->hits_cap();
     }
     if (!done) {
         if (q_end - q_begin > 1) {
@@ -272,13 +356,21 @@ static int collect_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_
             return collect_range(db, qs, mid, q_end, max_div, max_num_hits, out);
         }
         // one query with more rows than the buffer: it can have at most one row per subject
-        int rc = ensure_scratch(db, std::max<uint64_t>(count, db->n));
+        int rc = db->hits.ensure(std::max<uint64_t>(count, db->n) * sizeof(smafa_hit));
         if (rc) return rc;
         return collect_range(db, qs, q_begin, q_end, max_div, max_num_hits, out);
     }
+    if (count == 0) return SMAFA_OK;
+    bool sorted = false;
+    if (count >= 4096) {  // small lists are cheaper to order on the host
+        int rc = sort_rows_on_device(db, count, q_begin, q_end, &sorted);
+        if (rc) return rc;
+    }
     const size_t old = out.size();
     out.resize(old + count);
-    if (count) HIP_TRY(hipMemcpy(out.data() + old, db->d_hits, count * sizeof(smafa_hit), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(out.data() + old, db->hits.p, count * sizeof(smafa_hit), hipMemcpyDeviceToHost, db->stream));
+    HIP_TRY(hipStreamSynchronize(db->stream));
+    if (!sorted) std::sort(out.begin() + old, out.end(), hit_less);  // each range ordered => `out` ordered
     return SMAFA_OK;
 }
 
@@ -289,15 +381,15 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
     if (n_queries > 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many queries in one batch");
     int rc = use_device(db);
     if (rc) return rc;
-    rc = ensure_scratch(db, 1ull << 22);  // 4M rows = 48 MiB to start with
+    rc = db->count.ensure(sizeof(unsigned long long));
+    if (!rc && db->hits_cap() < (1ull << 22)) rc = db->hits.ensure((1ull << 22) * sizeof(smafa_hit));  // 4M rows = 48 MiB
     if (rc) return rc;
-    smafa_qset *qs = nullptr;
-    rc = smafa_qset_create(&qs, db, query_codes, n_queries);
+    rc = validate_codes(db, query_codes, n_queries);
     if (rc) return rc;
-    rc = collect_range(db, qs, 0, (uint32_t)n_queries, max_div, max_num_hits, out);
-    smafa_qset_destroy(qs);
+    rc = qset_fill(&db->scratch_q, db, query_codes, n_queries);
     if (rc) return rc;
-    std::sort(out.begin(), out.end(), hit_less);
+    rc = collect_range(db, &db->scratch_q, 0, (uint32_t)n_queries, max_div, max_num_hits, out);
+    if (rc) return rc;
     if (max_num_hits != SMAFA_NONE && max_num_hits >= 1) {
         // drop rows above the k-th smallest distance of their query (the device bound only tightens)
         size_t w = 0, i = 0;
@@ -371,6 +463,7 @@ int smafa_db_append(smafa_db *db, const uint8_t *codes, uint64_t n) {
     rc = pack_rows(db, codes, db->n, n, db->d_planes, 0);
     if (rc) return rc;
     db->n += n;
+    if (n > (1u << 20)) db->upload.release();  // a bulk load's staging buffer is not worth keeping
     return SMAFA_OK;
 }
 
@@ -395,13 +488,14 @@ int smafa_db_set_stream(smafa_db *db, void *hip_stream) {
 
 void smafa_db_destroy(smafa_db *db) {
     if (!db) return;
-    hipSetDevice(db->device);
-    if (db->d_planes) hipFree(db->d_planes);
-    if (db->d_hits) hipFree(db->d_hits);
-    if (db->d_count) hipFree(db->d_count);
-    if (db->ev0) hipEventDestroy(db->ev0);
-    if (db->ev1) hipEventDestroy(db->ev1);
-    if (db->own_stream) hipStreamDestroy(db->own_stream);
+    (void)hipSetDevice(db->device);
+    if (db->d_planes) (void)hipFree(db->d_planes);
+    for (DevBuf *b : {&db->upload, &db->hits, &db->count, &db->keys_a, &db->keys_b, &db->sort_tmp, &db->scratch_q.qrec,
+                      &db->scratch_q.thr, &db->scratch_q.cnt})
+        b->release();
+    if (db->ev0) (void)hipEventDestroy(db->ev0);
+    if (db->ev1) (void)hipEventDestroy(db->ev1);
+    if (db->own_stream) (void)hipStreamDestroy(db->own_stream);
     delete db;
 }
 
@@ -420,17 +514,7 @@ int smafa_qset_create(smafa_qset **out, smafa_db *db, const uint8_t *query_codes
     rc = validate_codes(db, query_codes, n_queries);
     if (rc) return rc;
     smafa_qset *qs = new smafa_qset();
-    qs->db = db;
-    qs->nq = n_queries;
-    const uint64_t padded = (n_queries + 63) / 64 * 64;
-    hipError_t e = hipMalloc(&qs->d_qrec, std::max<uint64_t>(padded, 64) * db->QS * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&qs->d_thr, std::max<uint64_t>(padded, 64) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemsetAsync(qs->d_qrec, 0, std::max<uint64_t>(padded, 64) * db->QS * sizeof(uint32_t), db->stream);
-    if (e != hipSuccess) {
-        smafa_qset_destroy(qs);
-        return set_error(SMAFA_ERR_DEVICE, "query set allocation failed: %s", hipGetErrorString(e));
-    }
-    rc = pack_rows(db, query_codes, 0, n_queries, qs->d_qrec, 1);
+    rc = qset_fill(qs, db, query_codes, n_queries);
     if (rc) {
         smafa_qset_destroy(qs);
         return rc;
@@ -441,10 +525,10 @@ int smafa_qset_create(smafa_qset **out, smafa_db *db, const uint8_t *query_codes
 
 void smafa_qset_destroy(smafa_qset *qs) {
     if (!qs) return;
-    if (qs->db) hipSetDevice(qs->db->device);
-    if (qs->d_qrec) hipFree(qs->d_qrec);
-    if (qs->d_thr) hipFree(qs->d_thr);
-    if (qs->d_cnt) hipFree(qs->d_cnt);
+    if (qs->db) (void)hipSetDevice(qs->db->device);
+    qs->qrec.release();
+    qs->thr.release();
+    qs->cnt.release();
     delete qs;
 }
 
@@ -496,22 +580,19 @@ int smafa_distances(smafa_db *db, const uint8_t *query_codes, uint32_t *distance
     if (db->n == 0) return SMAFA_OK;
     int rc = use_device(db);
     if (rc) return rc;
-    smafa_qset *qs = nullptr;
-    rc = smafa_qset_create(&qs, db, query_codes, 1);
+    rc = validate_codes(db, query_codes, 1);
+    if (rc) return rc;
+    rc = qset_fill(&db->scratch_q, db, query_codes, 1);
     if (rc) return rc;
     const uint32_t n_tiles = (uint32_t)((db->n + kWaveTile - 1) / kWaveTile);
-    uint4 *d_out = nullptr;
-    hipError_t e = hipMalloc(&d_out, (size_t)n_tiles * kWaveTile * sizeof(uint32_t));
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(distances_kernel, dim3((n_tiles + kWgWaves - 1) / kWgWaves), dim3(256), 0, db->stream,
-                           reinterpret_cast<const uint4 *>(db->d_planes), n_tiles, db->P, db->W, qs->d_qrec, d_out);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(distances, d_out, db->n * sizeof(uint32_t), hipMemcpyDeviceToHost, db->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
-    hipFree(d_out);
-    smafa_qset_destroy(qs);
-    if (e != hipSuccess) return set_error(SMAFA_ERR_DEVICE, "distances kernel failed: %s", hipGetErrorString(e));
+    rc = db->keys_a.ensure((size_t)n_tiles * kWaveTile * sizeof(uint32_t));  // any scratch buffer will do
+    if (rc) return rc;
+    hipLaunchKernelGGL(distances_kernel, dim3((n_tiles + kWgWaves - 1) / kWgWaves), dim3(256), 0, db->stream,
+                       reinterpret_cast<const uint4 *>(db->d_planes), n_tiles, db->P, db->W, db->scratch_q.qrec.as<uint32_t>(),
+                       db->keys_a.as<uint4>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(distances, db->keys_a.p, db->n * sizeof(uint32_t), hipMemcpyDeviceToHost, db->stream));
+    HIP_TRY(hipStreamSynchronize(db->stream));
     return SMAFA_OK;
 }
 

@@ -141,7 +141,7 @@ __device__ __forceinline__ uint32_t comp(const uint4 &v) {
 // If the prefilter stops paying (dense neighbourhoods: it passes for more than a quarter of a chunk's
 // queries) the wave switches to the plain full comparison and re-probes every 16th chunk.
 // ---------------------------------------------------------------------------------------------
-template <int P, int W>
+template <int P, int W, bool SEED>
 __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 *__restrict__ planes,
                                                    const uint32_t *__restrict__ qrec, ScanArgs a) {
     constexpr int RS = qrec_stride(P, W);  // words per record
@@ -221,6 +221,18 @@ __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 
             d[1] = (w ? d[1] : 0u) + __builtin_popcount(m1);
             d[2] = (w ? d[2] : 0u) + __builtin_popcount(m2);
             d[3] = (w ? d[3] : 0u) + __builtin_popcount(m3);
+        }
+        if (SEED) {
+            // seed pass for the running minimum (its own instantiation: keeps this code out of the hot kernel,
+            // where it cost 3.5 % through register allocation alone): one atomicMin per wave instead of one per qualifying pair
+            uint32_t lo = 0xffffffffu;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (subj0 + k < a.n_subjects) lo = min(lo, d[k]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+            if (lane == 0 && lo < U) atomicMin(a.thr + q, lo);
+            return;
         }
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -316,7 +328,6 @@ __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 
                 }
                 filter_on = passes * 4u <= nqc;
             } else {
-#pragma unroll 2
                 for (uint32_t i = 0; i < nqc; i++, rec += RV) {
                     uint32_t qw[RS];
                     read_record(rec, qw, 0, RV);
