@@ -159,54 +159,102 @@ int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t
     const size_t len = buf.size();
     uint64_t cnt = 0;
     if (!get_varint(p, len, pos, 10, cnt)) return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
-    // first pass: the words; the sequence length comes last in the file
-    std::vector<uint64_t> words;
+    // The sequence length comes LAST in the file (Option<NonZeroUsize> after the windows), but the first
+    // window's word count nw bounds it: (nw-1)*12 < L <= nw*12.  Windows are decoded straight into rows of
+    // nw*12 codes through a 32-entry table (one-hot 5 bits -> code; 254 = empty slot, 255 = invalid,
+    // src/lib.rs:120-129), then checked against L and compacted if L is not a multiple of 12.
+    static const struct OneHot {
+        uint8_t t[32];
+        OneHot() {
+            for (int i = 0; i < 32; i++) t[i] = 255;
+            t[0] = 254;
+            t[16] = 0, t[8] = 1, t[4] = 2, t[2] = 3, t[1] = 4;
+        }
+    } onehot;
     uint64_t nw = 0;
+    uint8_t *wide = nullptr;
+    size_t stride = 0;
     for (uint64_t j = 0; j < cnt; j++) {
         uint64_t k = 0;
-        if (!get_varint(p, len, pos, 10, k)) return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
+        if (!get_varint(p, len, pos, 10, k)) {
+            free(wide);
+            return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
+        }
         if (j == 0) {
             nw = k;
-            if (nw == 0 || cnt > (len / nw) + 1) return set_error(SMAFA_ERR_FORMAT, "%s: corrupt store", path);
-            words.reserve((size_t)cnt * nw);
+            if (nw == 0 || nw > (1u << 26) || cnt > len / nw + 1) return set_error(SMAFA_ERR_FORMAT, "%s: corrupt store", path);
+            stride = (size_t)nw * 12;
+            wide = (uint8_t *)malloc(std::max<size_t>((size_t)cnt * stride, 1));
+            if (!wide) return set_error(SMAFA_ERR_IO, "out of memory");
         } else if (k != nw) {
+            free(wide);
             return set_error(SMAFA_ERR_FORMAT, "%s: windows of unequal size", path);
         }
+        uint8_t *row = wide + (size_t)j * stride;
         for (uint64_t w = 0; w < nw; w++) {
             uint64_t v = 0;
-            if (!get_varint(p, len, pos, 10, v)) return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
-            words.push_back(v);
+            if (pos + 10 <= len) {  // fast path: a whole varint is in range, no per-byte bounds checks
+                const uint8_t *q = p + pos;
+                int i = 0;
+                for (; i < 10; i++) {
+                    v |= (uint64_t)(q[i] & 0x7f) << (7 * i);
+                    if (!(q[i] & 0x80)) break;
+                }
+                if (i == 10 || (i == 9 && q[9] > 1)) {
+                    free(wide);
+                    return set_error(SMAFA_ERR_FORMAT, "DeserializeBadVarint");
+                }
+                pos += (size_t)i + 1;
+            } else if (!get_varint(p, len, pos, 10, v)) {
+                free(wide);
+                return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
+            }
+            if (v >> 60) {  // 12 symbols x 5 bits: the top 4 bits are never set by from_bytes
+                free(wide);
+                return set_error(SMAFA_ERR_PANIC, "Invalid character in query sequence: %u", (unsigned)(v >> 60));
+            }
+            uint8_t *dst = row + w * 12;
+            for (int i = 0; i < 12; i++) dst[i] = onehot.t[(v >> (5 * i)) & 31u];
         }
     }
-    if (pos >= len) return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
+    if (pos >= len) {
+        free(wide);
+        return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
+    }
     const uint8_t tag = p[pos++];
     uint64_t L = 0;
     if (tag == 1) {
-        if (!get_varint(p, len, pos, 10, L) || L == 0) return set_error(SMAFA_ERR_FORMAT, "DeserializeBadEncoding");
+        if (!get_varint(p, len, pos, 10, L) || L == 0) {
+            free(wide);
+            return set_error(SMAFA_ERR_FORMAT, "DeserializeBadEncoding");
+        }
     } else if (tag != 0) {
+        free(wide);
         return set_error(SMAFA_ERR_FORMAT, "DeserializeBadOption");
     }
-    if (cnt && (L == 0 || (L + 11) / 12 != nw || L > 0xffffffffull))
+    if (cnt && (L == 0 || (L + 11) / 12 != nw || L > 0xffffffffull)) {
+        free(wide);
         return set_error(SMAFA_ERR_FORMAT, "%s: sequence length does not match the window size", path);
-    uint8_t *out = (uint8_t *)malloc(std::max<size_t>(cnt * L, 1));
-    if (!out) return set_error(SMAFA_ERR_IO, "out of memory");
-    for (uint64_t j = 0; j < cnt; j++) {
-        for (uint64_t i = 0; i < L; i++) {
-            const unsigned b = (unsigned)((words[j * nw + i / 12] >> (5 * (i % 12))) & 31u);
-            uint8_t c;
-            switch (b) {  // src/lib.rs:120-129
-            case 16: c = 0; break;
-            case 8: c = 1; break;
-            case 4: c = 2; break;
-            case 2: c = 3; break;
-            case 1: c = 4; break;
-            default:
-                free(out);
-                return set_error(SMAFA_ERR_PANIC, "Invalid character in query sequence: %u", b);
-            }
-            out[j * L + i] = c;
-        }
     }
+    // columns < L must hold a symbol (the reference's get_as_string panics otherwise); slots past L are ignored
+    uint8_t *out = wide;
+    for (uint64_t j = 0; j < cnt; j++) {
+        const uint8_t *row = wide + (size_t)j * stride;
+        uint8_t worst = 0;
+        for (uint64_t i = 0; i < L; i++) worst = row[i] > worst ? row[i] : worst;
+        if (worst > 4) {
+            unsigned bad = 0;
+            for (uint64_t i = 0; i < L; i++)
+                if (row[i] > 4) {
+                    bad = row[i] == 254 ? 0u : 31u;
+                    break;
+                }
+            free(wide);
+            return set_error(SMAFA_ERR_PANIC, "Invalid character in query sequence: %u", bad);
+        }
+        if (stride != L) memmove(out + (size_t)j * L, row, L);  // compact in place (L < stride, ascending j)
+    }
+    if (!out) out = (uint8_t *)malloc(1);
     *alphabet = SMAFA_ALPHABET_NT;
     *codes = out;
     *n = cnt;

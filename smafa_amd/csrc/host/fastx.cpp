@@ -70,11 +70,27 @@ int FastxReader::next(FastxRecord &rec) {
     if (rec.id_len && rec.id[rec.id_len - 1] == '\r') rec.id_len--;
     size_t p = after(he);
     seq_.clear();
+    // a line goes in with one bulk copy; carriage returns (rare) are squeezed out afterwards
     auto take_line = [&](size_t from, size_t to) {
-        for (size_t i = from; i < to; i++)
-            if (d[i] != '\r') seq_.push_back(d[i]);
+        const size_t base = seq_.size();
+        seq_.insert(seq_.end(), d + from, d + to);
+        if (to > from && memchr(d + from, '\r', to - from)) {
+            size_t w = base;
+            for (size_t i = base; i < seq_.size(); i++)
+                if (seq_[i] != '\r') seq_[w++] = seq_[i];
+            seq_.resize(w);
+        }
     };
     if (!fastq_) {
+        const size_t le0 = eol(p);
+        const size_t p2 = after(le0);
+        if ((p2 >= n || d[p2] == '>') && !(le0 > p && memchr(d + p, '\r', le0 - p))) {
+            // the common case — one sequence line, no CR: hand out the bytes in place, no copy
+            rec.seq = d + p;
+            rec.seq_len = le0 - p;
+            pos_ = p2;
+            return 1;
+        }
         while (p < n && d[p] != '>') {
             const size_t le = eol(p);
             take_line(p, le);
