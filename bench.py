@@ -170,9 +170,17 @@ def main() -> None:
             store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
         e1.record(stream)
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps  # includes the tiny threshold-fill + counter-reset launches
+        ms = e0.elapsed_time(e1) / reps  # includes the counter-reset launch and launch gaps
+        k_ms = []
+        for _ in range(20):  # kernel-only time: HIP events recorded by the library right around the scan kernel
+            store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
+            k_ms.append(store.last_scan_ms()[0])
+        k_med = float(np.median(k_ms))
         stream_info = {
             "ms_per_query": ms,
+            "kernel_ms_median": k_med,
+            "kernel_stored_GBs": info.hbm_bytes / k_med / 1e6,
+            "kernel_frac_of_peak_stored": info.hbm_bytes / k_med / 1e6 / HBM_PEAK_GBS,
             "stored_GBs": info.hbm_bytes / ms / 1e6,
             "algorithmic_GBs": N * L / ms / 1e6,
             "frac_of_peak_stored": info.hbm_bytes / ms / 1e6 / HBM_PEAK_GBS,

@@ -188,7 +188,7 @@ static uint32_t choose_query_block(const smafa_db *db, uint32_t n_wg_tiles, uint
 
 // one kernel launch: queries [q_begin, q_end) x wave tiles [tile_begin, tile_end)
 static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t tile_begin,
-                        uint32_t tile_end, uint32_t k_tight, smafa_hit *d_hits, uint64_t cap,
+                        uint32_t tile_end, uint32_t k_tight, uint32_t thr0, smafa_hit *d_hits, uint64_t cap,
                         unsigned long long *d_count) {
     ScanArgs a;
     a.tile_begin = tile_begin;
@@ -198,7 +198,8 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     a.q_begin = q_begin;
     a.q_end = q_end;
     a.qb_size = choose_query_block(db, a.n_wg_tiles, q_end - q_begin);
-    a.thr = qs->thr.as<uint32_t>();
+    a.thr = k_tight ? qs->thr.as<uint32_t>() : nullptr;  // fixed bound: no per-query array, no fill launch
+    a.thr0 = thr0;
     a.cnt = qs->cnt.as<uint32_t>();
     a.cnt_stride = db->L + 1;
     a.k_tight = k_tight;
@@ -230,8 +231,9 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     db->timed = false;
     if (nq == 0 || db->n == 0) return SMAFA_OK;
     const uint32_t thr0 = std::min<uint32_t>(max_div, db->L);  // a distance never exceeds seq_len
-    hipLaunchKernelGGL(fill_u32_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream, qs->thr.as<uint32_t>() + q_begin,
-                       thr0, (uint64_t)nq);
+    if (k_tight)
+        hipLaunchKernelGGL(fill_u32_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream,
+                           qs->thr.as<uint32_t>() + q_begin, thr0, (uint64_t)nq);
     const size_t cnt_stride = db->L + 1;
     auto zero_cnt = [&]() -> int {
         if (k_tight < 2) return SMAFA_OK;
@@ -245,18 +247,18 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     HIP_TRY(hipEventRecord(db->ev0, db->stream));
     int rc = SMAFA_OK;
     if (k_tight == 0) {
-        rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, d_hits, cap, d_count);
+        rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, thr0, d_hits, cap, d_count);
     } else {
         rc = zero_cnt();
         // seed: k = 1 reduces each wave's minimum before its single atomicMin, so a whole workgroup tile is
         // cheap; the k >= 2 seed counts every pair in its histogram, so keep it to one wave tile
         const uint32_t seed_tiles = std::min<uint32_t>(k_tight == 1 ? kWgWaves : 1, n_tiles);
-        if (!rc) rc = launch_tiles(db, qs, q_begin, q_end, 0, seed_tiles, k_tight, nullptr, 0, d_count);
+        if (!rc) rc = launch_tiles(db, qs, q_begin, q_end, 0, seed_tiles, k_tight, thr0, nullptr, 0, d_count);
         if (!rc) rc = zero_cnt();  // the seed's subjects are counted again below
         uint32_t begin = 0, len = kWgWaves;
         while (!rc && begin < n_tiles) {
             const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)begin + len, n_tiles);
-            rc = launch_tiles(db, qs, q_begin, q_end, begin, end, k_tight, d_hits, cap, d_count);
+            rc = launch_tiles(db, qs, q_begin, q_end, begin, end, k_tight, thr0, d_hits, cap, d_count);
             begin = end;
             len = len > (1u << 28) ? len : len * 8;
         }

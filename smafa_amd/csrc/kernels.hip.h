@@ -49,6 +49,9 @@ constexpr int kChunk = 64;      // queries staged in LDS at a time
 #ifndef SMAFA_MIN_WAVES
 #define SMAFA_MIN_WAVES 6  // __launch_bounds__ second argument: waves per SIMD the register budget must allow
 #endif
+#ifndef SMAFA_AND_PAIR
+#define SMAFA_AND_PAIR 1  // 1: the prefilter bounds two subjects with one popcount (weaker, cheaper: +5 % measured)
+#endif
 constexpr int kGroup = SMAFA_GROUP;
 
 __host__ __device__ constexpr int round_up4(int x) { return (x + 3) & ~3; }
@@ -69,7 +72,8 @@ struct ScanArgs {
     uint32_t n_subjects;
     uint32_t q_begin, q_end;  // query range of this launch
     uint32_t qb_size;         // queries per workgroup pass
-    uint32_t *thr;            // per-query emission bound (only ever lowered)
+    uint32_t *thr;            // per-query emission bound (only ever lowered); NULL: every query uses thr0
+    uint32_t thr0;            // the fixed bound of a launch without per-query bounds
     uint32_t *cnt;            // per-query histogram of emitted distances (k_tight >= 2), stride cnt_stride
     uint32_t cnt_stride;
     uint32_t k_tight;         // 0: bounds fixed; 1: lower to running minimum; k>=2: lower to running k-th
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 
             if (idx < nqc * RV) {
                 uint4 x = src[idx];
                 if (idx % RV == BS / 4) {  // the uint4 holding the bound slot: merge ~bound
-                    const uint32_t nu = ~ld_relaxed(a.thr + qc + idx / RV);
+                    const uint32_t nu = ~(a.thr ? ld_relaxed(a.thr + qc + idx / RV) : a.thr0);
                     if ((BS & 3) == 0) x.x = nu;
                     else if ((BS & 3) == 1) x.y = nu;
                     else if ((BS & 3) == 2) x.z = nu;
@@ -295,9 +299,15 @@ __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 
                             m3 = or_xor(m3, s[FP * W + w].w, head[j][w]);
                         }
                         const uint32_t nu = head[j][BS];
+#if SMAFA_AND_PAIR
+                        // popcount(a & b) <= min(popcount a, popcount b): one popcount bounds two subjects
+                        const uint32_t t0 = __builtin_popcount(m0 & m1) + nu, t2 = __builtin_popcount(m2 & m3) + nu;
+                        any[j] = j ? or3(t0, t2, any[j - 1]) : (t0 | t2);
+#else
                         const uint32_t t0 = __builtin_popcount(m0) + nu, t1 = __builtin_popcount(m1) + nu;
                         const uint32_t t2 = __builtin_popcount(m2) + nu, t3 = __builtin_popcount(m3) + nu;
                         any[j] = j ? or3(or3(t0, t1, t2), t3, any[j - 1]) : (or3(t0, t1, t2) | t3);  // running OR
+#endif
                     }
                     if (__ballot((int32_t)any[kGroup - 1] < 0) != 0ull) {  // wave-uniform, rare
 #pragma unroll
@@ -316,8 +326,12 @@ __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 
                                 m3 = or_xor(m3, s[FP * W + w].w, qw[w]);
                             }
                             const uint32_t nu = qw[BS];
+#if SMAFA_AND_PAIR
+                            const uint32_t own = (__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu);
+#else
                             const uint32_t own = or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
                                                      __builtin_popcount(m2) + nu) | (__builtin_popcount(m3) + nu);
+#endif
                             if (i + j < nqc && __ballot((int32_t)own < 0) != 0ull) {
                                 passes++;
                                 read_record(rec + j * RV, qw, HV, RV);
@@ -356,7 +370,7 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(const uint4 *__restri
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
     const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
     for (uint32_t q = q0; q < q1; q++) {
-        const uint32_t U = ld_relaxed(a.thr + q);
+        const uint32_t U = a.thr ? ld_relaxed(a.thr + q) : a.thr0;
         const uint32_t *qr = qrec + (size_t)q * QS;
         uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
         for (uint32_t w = 0; w < W; w++) {
