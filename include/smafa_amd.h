@@ -57,7 +57,7 @@ typedef struct {
     uint32_t seq_len;
     int32_t alphabet;
     int32_t device;
-    uint32_t planes;          /* bit-planes per symbol: 3 (NT) or 5 (AA) */
+    uint32_t planes;          /* bit-planes stored per subject: 5 (AA), 3 (NT), or 2 (NT store without any N) */
     uint32_t words_per_plane; /* ceil(seq_len / 32) */
     uint64_t hbm_bytes;       /* bytes of the packed subject block in HBM */
     uint64_t bytes_per_subject;

@@ -20,7 +20,8 @@ namespace smafa {
         if (e_ != hipSuccess) return set_error(SMAFA_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-static int planes_for(int alphabet) { return alphabet == SMAFA_ALPHABET_AA ? 5 : 3; }
+// planes per query record: 3 code bits for ACGTN, 5 for the amino-acid codes 0..27
+static int query_planes_for(int alphabet) { return alphabet == SMAFA_ALPHABET_AA ? 5 : 3; }
 
 // grow-only device buffer (scratch that is reused across calls: hipMalloc/hipFree cost far more than a scan)
 struct DevBuf {
@@ -58,7 +59,9 @@ struct smafa_qset {
 struct smafa_db {
     int device = 0;
     int alphabet = 0;
-    uint32_t L = 0, P = 0, W = 0, QS = 0;
+    uint32_t L = 0, W = 0, QS = 0;
+    uint32_t P = 0;   // planes stored per SUBJECT: 5 (aa), 3 (nt), or 2 while no nucleotide subject holds an N
+    uint32_t PQ = 0;  // planes per QUERY record: 5 (aa) or 3 (nt)
     uint64_t n = 0;          // subjects stored
     uint64_t cap_tiles = 0;  // allocated wave tiles
     uint32_t *d_planes = nullptr;
@@ -95,11 +98,15 @@ static int pack_rows(smafa_db *db, const uint8_t *codes, uint64_t first, uint64_
     HIP_TRY(hipMemcpyAsync(d_codes, codes, bytes, hipMemcpyHostToDevice, db->stream));
     const uint64_t groups = (first + n + 63) / 64 - first / 64;
     const uint32_t blocks = (uint32_t)((groups + kWgWaves - 1) / kWgWaves);
-    if (db->P == 5)
+    const uint32_t planes = mode == 0 ? db->P : db->PQ;  // subjects may be stored with fewer planes than queries
+    if (planes == 5)
         hipLaunchKernelGGL(pack_rows_kernel<5>, dim3(blocks), dim3(256), 0, db->stream, d_codes, first, n, db->L, db->W,
                            d_out, mode, db->QS);
-    else
+    else if (planes == 3)
         hipLaunchKernelGGL(pack_rows_kernel<3>, dim3(blocks), dim3(256), 0, db->stream, d_codes, first, n, db->L, db->W,
+                           d_out, mode, db->QS);
+    else
+        hipLaunchKernelGGL(pack_rows_kernel<2>, dim3(blocks), dim3(256), 0, db->stream, d_codes, first, n, db->L, db->W,
                            d_out, mode, db->QS);
     HIP_TRY(hipGetLastError());
     // the caller's host buffer is borrowed for the call only, and `upload` is reused by the next call
@@ -107,12 +114,31 @@ static int pack_rows(smafa_db *db, const uint8_t *codes, uint64_t first, uint64_
     return SMAFA_OK;
 }
 
-static int validate_codes(const smafa_db *db, const uint8_t *codes, uint64_t n) {
+static int validate_codes(const smafa_db *db, const uint8_t *codes, uint64_t n, uint8_t *max_code = nullptr) {
     const uint8_t lim = db->alphabet == SMAFA_ALPHABET_AA ? 28 : 5;
     const size_t total = (size_t)n * db->L;
     uint8_t worst = 0;
     for (size_t i = 0; i < total; i++) worst = codes[i] > worst ? codes[i] : worst;
     if (worst >= lim) return set_error(SMAFA_ERR_INVALID, "code byte %u outside the alphabet (max %u)", worst, lim - 1);
+    if (max_code) *max_code = worst;
+    return SMAFA_OK;
+}
+
+// 2-plane (N-free) nucleotide store -> 3 planes, in place of the old block
+static int upgrade_planes(smafa_db *db, uint32_t p_new) {
+    if (db->P >= p_new) return SMAFA_OK;
+    if (db->cap_tiles) {
+        uint32_t *d_new = nullptr;
+        const size_t words = db->cap_tiles * (size_t)p_new * db->W * kWaveTile;
+        HIP_TRY(hipMalloc(&d_new, words * sizeof(uint32_t)));
+        hipLaunchKernelGGL(replane_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, db->stream, db->d_planes,
+                           d_new, db->cap_tiles, db->P, p_new, db->W);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(db->stream));
+        HIP_TRY(hipFree(db->d_planes));
+        db->d_planes = d_new;
+    }
+    db->P = p_new;
     return SMAFA_OK;
 }
 
@@ -149,28 +175,29 @@ static int qset_fill(smafa_qset *qs, smafa_db *db, const uint8_t *query_codes, u
     return pack_rows(db, query_codes, 0, n_queries, qs->qrec.as<uint32_t>(), 1);
 }
 
-template <int P, int W>
+template <int PS, int PQ, int W>
 static void launch_scan_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
     // the seed pass of the running-minimum mode (no append) has its own instantiation
     if (a.hits == nullptr && a.k_tight == 1)
-        hipLaunchKernelGGL((scan_kernel<P, W, true>), dim3(grid), dim3(256), 0, db->stream,
+        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, true>), dim3(grid), dim3(256), 0, db->stream,
                            reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
     else
-        hipLaunchKernelGGL((scan_kernel<P, W, false>), dim3(grid), dim3(256), 0, db->stream,
+        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, false>), dim3(grid), dim3(256), 0, db->stream,
                            reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
 }
 
 static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
-#define SMAFA_CASE(P_, W_)                          \
-    if (db->P == P_ && db->W == W_) {               \
-        launch_scan_t<P_, W_>(db, d_qrec, a, grid); \
-        return;                                     \
+#define SMAFA_CASE(PS_, PQ_, W_)                          \
+    if (db->P == PS_ && db->PQ == PQ_ && db->W == W_) {   \
+        launch_scan_t<PS_, PQ_, W_>(db, d_qrec, a, grid); \
+        return;                                           \
     }
-    SMAFA_CASE(3, 1) SMAFA_CASE(3, 2) SMAFA_CASE(3, 3) SMAFA_CASE(3, 4)
-    SMAFA_CASE(5, 1) SMAFA_CASE(5, 2) SMAFA_CASE(5, 3) SMAFA_CASE(5, 4)
+    SMAFA_CASE(2, 3, 1) SMAFA_CASE(2, 3, 2) SMAFA_CASE(2, 3, 3) SMAFA_CASE(2, 3, 4)
+    SMAFA_CASE(3, 3, 1) SMAFA_CASE(3, 3, 2) SMAFA_CASE(3, 3, 3) SMAFA_CASE(3, 3, 4)
+    SMAFA_CASE(5, 5, 1) SMAFA_CASE(5, 5, 2) SMAFA_CASE(5, 5, 3) SMAFA_CASE(5, 5, 4)
 #undef SMAFA_CASE
     hipLaunchKernelGGL(scan_generic_kernel, dim3(grid), dim3(256), 0, db->stream,
-                       reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a, db->P, db->W, db->QS);
+                       reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a, db->P, db->PQ, db->W, db->QS);
 }
 
 // queries per workgroup pass: big enough that the tile load is amortised (the scan is then bound by
@@ -434,9 +461,14 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     db->device = device;
     db->alphabet = alphabet;
     db->L = seq_len;
-    db->P = (uint32_t)planes_for(alphabet);
+    db->PQ = (uint32_t)query_planes_for(alphabet);
+    // nucleotide stores start in the 2-bit form (A C G T only) and gain the N plane when an N is appended
+    db->P = alphabet == SMAFA_ALPHABET_NT ? 2u : db->PQ;
+    if (const char *pv = getenv("SMAFA_NT_PLANES")) {  // testing: force the 3-plane store
+        if (alphabet == SMAFA_ALPHABET_NT && atoi(pv) == 3) db->P = 3;
+    }
     db->W = (seq_len + 31) / 32;
-    db->QS = (uint32_t)qrec_stride((int)db->P, (int)db->W);
+    db->QS = (uint32_t)qrec_stride((int)db->PQ, (int)db->W);
     if (const char *fv = getenv("SMAFA_FILTER")) db->use_filter = atoi(fv) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) db->n_cu = prop.multiProcessorCount;
@@ -458,8 +490,13 @@ int smafa_db_append(smafa_db *db, const uint8_t *codes, uint64_t n) {
     if (db->n + n > 0xffffff00ull) return set_error(SMAFA_ERR_INVALID, "subject store limited to 2^32 rows");
     int rc = use_device(db);
     if (rc) return rc;
-    rc = validate_codes(db, codes, n);
+    uint8_t max_code = 0;
+    rc = validate_codes(db, codes, n, &max_code);
     if (rc) return rc;
+    if (db->alphabet == SMAFA_ALPHABET_NT && max_code >= 4 && db->P < 3) {  // first N: leave the 2-bit form
+        rc = upgrade_planes(db, 3);
+        if (rc) return rc;
+    }
     rc = reserve_tiles(db, (db->n + n + kWaveTile - 1) / kWaveTile);
     if (rc) return rc;
     rc = pack_rows(db, codes, db->n, n, db->d_planes, 0);
@@ -590,8 +627,8 @@ int smafa_distances(smafa_db *db, const uint8_t *query_codes, uint32_t *distance
     rc = db->keys_a.ensure((size_t)n_tiles * kWaveTile * sizeof(uint32_t));  // any scratch buffer will do
     if (rc) return rc;
     hipLaunchKernelGGL(distances_kernel, dim3((n_tiles + kWgWaves - 1) / kWgWaves), dim3(256), 0, db->stream,
-                       reinterpret_cast<const uint4 *>(db->d_planes), n_tiles, db->P, db->W, db->scratch_q.qrec.as<uint32_t>(),
-                       db->keys_a.as<uint4>());
+                       reinterpret_cast<const uint4 *>(db->d_planes), n_tiles, db->P, db->PQ, db->W,
+                       db->scratch_q.qrec.as<uint32_t>(), db->keys_a.as<uint4>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(distances, db->keys_a.p, db->n * sizeof(uint32_t), hipMemcpyDeviceToHost, db->stream));
     HIP_TRY(hipStreamSynchronize(db->stream));

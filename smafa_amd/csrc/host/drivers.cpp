@@ -83,7 +83,6 @@ struct FreeGuard {
 class RowSet {
   public:
     RowSet(const uint8_t *rows, uint32_t L) : rows_(rows), L_(L), slots_(1024, UINT32_MAX) {}
-    void rebase(const uint8_t *rows) { rows_ = rows; }
     // true if row `idx` was not present before
     bool insert(uint32_t idx) {
         if ((count_ + 1) * 2 > slots_.size()) grow();

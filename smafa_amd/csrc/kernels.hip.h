@@ -41,13 +41,15 @@ namespace smafa {
 
 constexpr int kWaveTile = 256;  // subjects per wave tile
 constexpr int kWgWaves = 4;     // waves per workgroup
-constexpr int kWgTile = kWaveTile * kWgWaves;
 constexpr int kChunk = 64;      // queries staged in LDS at a time
 #ifndef SMAFA_GROUP
 #define SMAFA_GROUP 1  // queries per fast-path step (one compare + branch per group); 1 measured best, profiles/r01_variant_matrix.txt
 #endif
 #ifndef SMAFA_MIN_WAVES
 #define SMAFA_MIN_WAVES 6  // __launch_bounds__ second argument: waves per SIMD the register budget must allow
+#endif
+#ifndef SMAFA_VADDR
+#define SMAFA_VADDR 1  // 1: fast-path LDS record address kept in a VGPR (saves a slow-class v_mov per query)
 #endif
 #ifndef SMAFA_AND_PAIR
 #define SMAFA_AND_PAIR 1  // 1: the prefilter bounds two subjects with one popcount (weaker, cheaper: +5 % measured)
@@ -124,11 +126,6 @@ __device__ __forceinline__ void emit(const ScanArgs &a, uint32_t q, uint32_t sub
     }
 }
 
-template <int K>
-__device__ __forceinline__ uint32_t comp(const uint4 &v) {
-    return K == 0 ? v.x : K == 1 ? v.y : K == 2 ? v.z : v.w;
-}
-
 // ---------------------------------------------------------------------------------------------
 // The scan: one workgroup = 4 waves = 1024 subjects x one block of queries.
 //
@@ -145,13 +142,16 @@ __device__ __forceinline__ uint32_t comp(const uint4 &v) {
 // If the prefilter stops paying (dense neighbourhoods: it passes for more than a quarter of a chunk's
 // queries) the wave switches to the plain full comparison and re-probes every 16th chunk.
 // ---------------------------------------------------------------------------------------------
-template <int P, int W, bool SEED>
+// PS = planes stored per subject, PQ = planes per query record (PS < PQ only for the N-free nucleotide
+// store: subjects carry code bits 0-1, queries still carry the N bit, which mismatches every subject).
+template <int PS, int PQ, int W, bool SEED>
 __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 *__restrict__ planes,
                                                    const uint32_t *__restrict__ qrec, ScanArgs a) {
-    constexpr int RS = qrec_stride(P, W);  // words per record
-    constexpr int RV = RS / 4;             // uint4 per record
+    constexpr int RS = qrec_stride(PQ, W);  // words per record
+    constexpr int RV = RS / 4;              // uint4 per record
     constexpr int NV = (kChunk * RV + 255) / 256;
-    constexpr int FP = filter_plane(P);
+    constexpr int FP = filter_plane(PQ);
+    static_assert(FP < PS && PS <= PQ, "the filter plane must be one the subjects store");
     constexpr int BS = bound_slot(W);
     constexpr int HV = (W + 1 + 3) / 4;  // uint4s holding the filter words + bound slot
     __shared__ uint4 stage[2][kChunk * RV];
@@ -164,11 +164,11 @@ __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 
     const uint32_t tile = a.tile_begin + wg_tile * kWgWaves + wave;
     const bool active = tile < a.tile_end;  // idle waves still take part in staging and barriers
 
-    uint4 s[P * W];
+    uint4 s[PS * W];
     {
-        const uint4 *t = planes + (size_t)(active ? tile : a.tile_begin) * (P * W * 64) + lane;
+        const uint4 *t = planes + (size_t)(active ? tile : a.tile_begin) * (PS * W * 64) + lane;
 #pragma unroll
-        for (int i = 0; i < P * W; i++) s[i] = t[i * 64];
+        for (int i = 0; i < PS * W; i++) s[i] = t[i * 64];
     }
     const uint32_t subj0 = tile * kWaveTile + lane * 4u;
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
@@ -211,15 +211,19 @@ __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 
         uint32_t d[4];
 #pragma unroll
         for (int w = 0; w < W; w++) {
-            uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+            uint32_t extra = 0;  // query bits in planes no subject has: a mismatch against every subject
 #pragma unroll
-            for (int p = 0; p < P; p++) {
+            for (int p = PS; p < PQ; p++) extra |= qw[qslot(PQ, W, p, w)];
+            uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
+#pragma unroll
+            for (int p = 0; p < PS; p++) {
                 const uint4 v = s[p * W + w];
-                const uint32_t qv = qw[qslot(P, W, p, w)];
-                m0 = p ? or_xor(m0, v.x, qv) : (v.x ^ qv);
-                m1 = p ? or_xor(m1, v.y, qv) : (v.y ^ qv);
-                m2 = p ? or_xor(m2, v.z, qv) : (v.z ^ qv);
-                m3 = p ? or_xor(m3, v.w, qv) : (v.w ^ qv);
+                const uint32_t qv = qw[qslot(PQ, W, p, w)];
+                const bool first = p == 0 && PS == PQ;
+                m0 = first ? (v.x ^ qv) : or_xor(m0, v.x, qv);
+                m1 = first ? (v.y ^ qv) : or_xor(m1, v.y, qv);
+                m2 = first ? (v.z ^ qv) : or_xor(m2, v.z, qv);
+                m3 = first ? (v.w ^ qv) : or_xor(m3, v.w, qv);
             }
             d[0] = (w ? d[0] : 0u) + __builtin_popcount(m0);
             d[1] = (w ? d[1] : 0u) + __builtin_popcount(m1);
@@ -272,14 +276,26 @@ __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 
                 uint32_t passes = 0;  // wave-uniform: queries of this chunk that needed the full comparison
                 // kGroup queries per step: their sign words are OR-ed into one, so the common case costs one
                 // compare + one branch per group.  Records past nqc are zero (bound slot 0 => never pass).
+#if SMAFA_VADDR
+                // The record address lives in a VGPR and advances with an all-VGPR add: hipcc would otherwise keep
+                // it scalar and pay one v_mov s->v (slow issue class) per query for the ds_read address.
+                uint32_t voff = (uint32_t)buf * (kChunk * RV * 16u), vstep = kGroup * RV * 16u;
+                asm volatile("" : "+v"(voff), "+v"(vstep));
+#endif
                 for (uint32_t i = 0; i < nqc; i += kGroup, rec += kGroup * RV) {
                     uint32_t head[kGroup][4 * HV];
                     uint32_t any[kGroup];
+#if SMAFA_VADDR
+                    const uint4 *hrec = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(&stage[0][0]) + voff);
+                    voff += vstep;
+#else
+                    const uint4 *hrec = rec;
+#endif
 #pragma unroll
                     for (int j = 0; j < kGroup; j++) {
 #pragma unroll
                         for (int v = 0; v < HV; v++) {
-                            const uint4 x = rec[j * RV + v];
+                            const uint4 x = hrec[j * RV + v];
                             head[j][4 * v + 0] = x.x;
                             head[j][4 * v + 1] = x.y;
                             head[j][4 * v + 2] = x.z;
@@ -357,15 +373,15 @@ __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 
 // Any (planes, words) shape: subject words are re-read from the tile (L1/L2) per query instead of
 // being held in registers.  Correct for every seq_len; used when no specialisation exists.
 __global__ __launch_bounds__(256) void scan_generic_kernel(const uint4 *__restrict__ planes,
-                                                           const uint32_t *__restrict__ qrec, ScanArgs a, uint32_t P,
-                                                           uint32_t W, uint32_t QS) {
+                                                           const uint32_t *__restrict__ qrec, ScanArgs a, uint32_t PS,
+                                                           uint32_t PQ, uint32_t W, uint32_t QS) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t wg_tile = blockIdx.x % a.n_wg_tiles;
     const uint32_t qblock = blockIdx.x / a.n_wg_tiles;
     const uint32_t tile = a.tile_begin + wg_tile * kWgWaves + wave;
     if (tile >= a.tile_end) return;  // no barrier in this kernel
-    const uint4 *t = planes + (size_t)tile * ((size_t)P * W * 64) + lane;
+    const uint4 *t = planes + (size_t)tile * ((size_t)PS * W * 64) + lane;
     const uint32_t subj0 = tile * kWaveTile + lane * 4u;
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
     const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
@@ -374,10 +390,12 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(const uint4 *__restri
         const uint32_t *qr = qrec + (size_t)q * QS;
         uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
         for (uint32_t w = 0; w < W; w++) {
-            uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-            for (uint32_t p = 0; p < P; p++) {
+            uint32_t extra = 0;
+            for (uint32_t p = PS; p < PQ; p++) extra |= qr[qslot((int)PQ, (int)W, (int)p, (int)w)];
+            uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
+            for (uint32_t p = 0; p < PS; p++) {
                 const uint4 v = t[(p * W + w) * 64];
-                const uint32_t qv = qr[qslot((int)P, (int)W, (int)p, (int)w)];
+                const uint32_t qv = qr[qslot((int)PQ, (int)W, (int)p, (int)w)];
                 m0 = or_xor(m0, v.x, qv);
                 m1 = or_xor(m1, v.y, qv);
                 m2 = or_xor(m2, v.z, qv);
@@ -398,18 +416,20 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(const uint4 *__restri
 // The literal get_distances seam (src/lib.rs:71-89): every subject's distance to ONE query.
 // out has n_wave_tiles * 256 entries (padded), one coalesced 16-byte store per lane.
 __global__ __launch_bounds__(256) void distances_kernel(const uint4 *__restrict__ planes, uint32_t n_wave_tiles,
-                                                        uint32_t P, uint32_t W, const uint32_t *__restrict__ qrec,
-                                                        uint4 *__restrict__ out) {
+                                                        uint32_t PS, uint32_t PQ, uint32_t W,
+                                                        const uint32_t *__restrict__ qrec, uint4 *__restrict__ out) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tile = blockIdx.x * kWgWaves + (threadIdx.x >> 6);
     if (tile >= n_wave_tiles) return;
-    const uint4 *t = planes + (size_t)tile * ((size_t)P * W * 64) + lane;
+    const uint4 *t = planes + (size_t)tile * ((size_t)PS * W * 64) + lane;
     uint4 d = make_uint4(0, 0, 0, 0);
     for (uint32_t w = 0; w < W; w++) {
-        uint4 m = make_uint4(0, 0, 0, 0);
-        for (uint32_t p = 0; p < P; p++) {
+        uint32_t extra = 0;
+        for (uint32_t p = PS; p < PQ; p++) extra |= qrec[qslot((int)PQ, (int)W, (int)p, (int)w)];
+        uint4 m = make_uint4(extra, extra, extra, extra);
+        for (uint32_t p = 0; p < PS; p++) {
             const uint4 v = t[(p * W + w) * 64];
-            const uint32_t qv = qrec[qslot((int)P, (int)W, (int)p, (int)w)];
+            const uint32_t qv = qrec[qslot((int)PQ, (int)W, (int)p, (int)w)];
             m.x = or_xor(m.x, v.x, qv);
             m.y = or_xor(m.y, v.y, qv);
             m.z = or_xor(m.z, v.z, qv);
@@ -479,6 +499,18 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *codes, ui
             }
         }
     }
+}
+
+// Re-layout the subject block from p_old to p_new planes per subject (new planes zero): the N-free
+// nucleotide store gains its third plane the first time a subject with an N is appended.
+__global__ void replane_kernel(const uint32_t *src, uint32_t *dst, uint64_t n_tiles, uint32_t p_old, uint32_t p_new,
+                               uint32_t W) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one u32 of dst
+    const uint64_t per_tile = (uint64_t)p_new * W * 256;
+    if (i >= n_tiles * per_tile) return;
+    const uint64_t tile = i / per_tile, r = i % per_tile;
+    const uint32_t p = (uint32_t)(r / (W * 256u)), rest = (uint32_t)(r % (W * 256u));
+    dst[i] = p < p_old ? src[tile * (uint64_t)p_old * W * 256 + (uint64_t)p * W * 256 + rest] : 0u;
 }
 
 __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {

@@ -81,7 +81,6 @@ def test_sharded_query_hip_scanner_equals_oracle(tmp_path):
     flags = ["--max-divergence", "6", "--max-num-hits", "3"]
     want = oracle.run_cli("query", "-d", db, "-q", qf, *flags)
     out = str(tmp_path / "out.tsv")
-    env_rank0 = dict(os.environ)
     r = run_world(2, db, qf, out, flags, hip=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(out).read() == want.stdout

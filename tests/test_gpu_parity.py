@@ -364,3 +364,53 @@ def test_python_api_query_and_cluster(golden, tmp_path):
     finally:
         os.close(fd)
     assert out.read_text() == FOUR + "ATGC\tATGC\nATGG\tATGC\nAAAA\tAAAA\n"
+
+
+# ------------------------------------------------- 2-bit (N-free) nucleotide store and its upgrade
+def test_nt_store_uses_two_planes_until_an_N_arrives():
+    """BASELINE configs[2] "2-bit pack path": a nucleotide store with no N keeps 2 planes per subject (16 B at
+    L=60); queries may still contain N (an N mismatches every subject).  The first appended N re-lays the store
+    out with 3 planes; results equal the 5-symbol oracle at every stage."""
+    rng = np.random.default_rng(31)
+    L = 60
+    s1 = rng.integers(0, 4, size=(3000, L), dtype=np.uint8)            # A C G T only
+    q = s1[rng.integers(0, 3000, size=80)].copy()
+    q[rng.random(size=q.shape) < 0.02] = 4                              # queries with N
+    for r in q[:40]:
+        for _ in range(rng.integers(0, 5)):
+            r[rng.integers(0, L)] = rng.integers(0, 4)
+    store = smafa_amd.SubjectStore(L, smafa_amd.ALPHABET_NT)
+    store.push(s1)
+    info = store.info()
+    assert info.planes == 2 and info.bytes_per_subject == 16
+    for D in (0, 3, 8, L):
+        assert store.scan(q, max_divergence=D).tobytes() == oracle.scan_codes(s1, q, D).tobytes()
+    assert (store.get_distances(q[5]) == oracle.distances_codes(s1, q[5])).all()
+    assert store.scan(q, None, 1).tobytes() == expected_with_k(oracle.scan_codes(s1, q, L), 1).tobytes()
+    # the reference's own arithmetic on the ASCII form
+    assert store.scan(q, max_divergence=4).tobytes() == oracle.scan_onehot(NT_ASCII[s1], NT_ASCII[q], 4).tobytes()
+    # now subjects with N arrive: 3 planes, old rows intact
+    s2 = rng.integers(0, 5, size=(700, L), dtype=np.uint8)
+    s2[:10] = q[:10]                                                    # exact copies, N included
+    store.push(s2)
+    info = store.info()
+    assert info.planes == 3 and info.bytes_per_subject == 24 and info.n_subjects == 3700
+    both = np.concatenate([s1, s2])
+    for D in (0, 3, L):
+        assert store.scan(q, max_divergence=D).tobytes() == oracle.scan_codes(both, q, D).tobytes()
+    assert (store.get_distances(q[0]) == oracle.distances_codes(both, q[0])).all()
+    store.close()
+
+
+@pytest.mark.parametrize("L", [7, 33, 100, 140])
+def test_nt_two_plane_store_other_lengths(L):
+    rng = np.random.default_rng(32 + L)
+    s = rng.integers(0, 4, size=(1500, L), dtype=np.uint8)
+    q = s[rng.integers(0, 1500, size=40)].copy()
+    q[:, L // 2] = 4
+    store = smafa_amd.SubjectStore(L, 0)
+    store.push(s)
+    assert store.info().planes == 2
+    for D in (1, 4):
+        assert store.scan(q, max_divergence=D).tobytes() == oracle.scan_codes(s, q, D).tobytes()
+    store.close()
