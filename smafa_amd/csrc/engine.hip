@@ -71,6 +71,7 @@ struct smafa_db {
     uint32_t last_launches = 0;
     uint32_t qb_override = 0;
     bool use_filter = true;  // exact lower-bound prefilter in the scan kernel (SMAFA_FILTER=0 disables)
+    uint32_t tiles_override = 0;  // SMAFA_TILES
     int n_cu = 256;
     // scratch of the host-buffer API, kept across calls
     DevBuf upload;            // staging for code rows on their way to the pack kernel
@@ -175,26 +176,36 @@ static int qset_fill(smafa_qset *qs, smafa_db *db, const uint8_t *query_codes, u
     return pack_rows(db, query_codes, 0, n_queries, qs->qrec.as<uint32_t>(), 1);
 }
 
-template <int PS, int PQ, int W>
+template <int PS, int PQ, int W, int T>
 static void launch_scan_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
     // the seed pass of the running-minimum mode (no append) has its own instantiation
     if (a.hits == nullptr && a.k_tight == 1)
-        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, true>), dim3(grid), dim3(256), 0, db->stream,
+        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, true>), dim3(grid), dim3(256), 0, db->stream,
                            reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
     else
-        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, false>), dim3(grid), dim3(256), 0, db->stream,
+        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, false>), dim3(grid), dim3(256), 0, db->stream,
                            reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
 }
 
-static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
-#define SMAFA_CASE(PS_, PQ_, W_)                          \
-    if (db->P == PS_ && db->PQ == PQ_ && db->W == W_) {   \
-        launch_scan_t<PS_, PQ_, W_>(db, d_qrec, a, grid); \
-        return;                                           \
+// wave tiles per wave (4*T subjects per lane): 2 where the specialisation exists and the extra subject words
+// keep the kernel at >= 6 waves per SIMD; SMAFA_TILES=1|2 overrides (measurements: profiles/)
+static uint32_t tiles_per_wave(const smafa_db *db) {
+    if (db->W > 2) return 1;
+    if (db->tiles_override) return db->tiles_override;
+    return scan_min_waves((int)db->P, (int)db->W, 2) >= 6 ? 2u : 1u;
+}
+
+static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid, uint32_t T) {
+#define SMAFA_CASE(PS_, PQ_, W_, T_)                          \
+    if (db->P == PS_ && db->PQ == PQ_ && db->W == W_ && T == T_) { \
+        launch_scan_t<PS_, PQ_, W_, T_>(db, d_qrec, a, grid); \
+        return;                                               \
     }
-    SMAFA_CASE(2, 3, 1) SMAFA_CASE(2, 3, 2) SMAFA_CASE(2, 3, 3) SMAFA_CASE(2, 3, 4)
-    SMAFA_CASE(3, 3, 1) SMAFA_CASE(3, 3, 2) SMAFA_CASE(3, 3, 3) SMAFA_CASE(3, 3, 4)
-    SMAFA_CASE(5, 5, 1) SMAFA_CASE(5, 5, 2) SMAFA_CASE(5, 5, 3) SMAFA_CASE(5, 5, 4)
+    SMAFA_CASE(2, 3, 1, 1) SMAFA_CASE(2, 3, 2, 1) SMAFA_CASE(2, 3, 3, 1) SMAFA_CASE(2, 3, 4, 1)
+    SMAFA_CASE(3, 3, 1, 1) SMAFA_CASE(3, 3, 2, 1) SMAFA_CASE(3, 3, 3, 1) SMAFA_CASE(3, 3, 4, 1)
+    SMAFA_CASE(5, 5, 1, 1) SMAFA_CASE(5, 5, 2, 1) SMAFA_CASE(5, 5, 3, 1) SMAFA_CASE(5, 5, 4, 1)
+    SMAFA_CASE(2, 3, 1, 2) SMAFA_CASE(2, 3, 2, 2) SMAFA_CASE(3, 3, 1, 2) SMAFA_CASE(3, 3, 2, 2)
+    SMAFA_CASE(5, 5, 1, 2) SMAFA_CASE(5, 5, 2, 2)
 #undef SMAFA_CASE
     hipLaunchKernelGGL(scan_generic_kernel, dim3(grid), dim3(256), 0, db->stream,
                        reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a, db->P, db->PQ, db->W, db->QS);
@@ -218,9 +229,11 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
                         uint32_t tile_end, uint32_t k_tight, uint32_t thr0, smafa_hit *d_hits, uint64_t cap,
                         unsigned long long *d_count) {
     ScanArgs a;
+    const bool specialised = db->W <= 4;  // else scan_generic_kernel: one wave tile per wave
+    const uint32_t T = specialised ? tiles_per_wave(db) : 1u;
     a.tile_begin = tile_begin;
     a.tile_end = tile_end;
-    a.n_wg_tiles = (tile_end - tile_begin + kWgWaves - 1) / kWgWaves;
+    a.n_wg_tiles = (tile_end - tile_begin + kWgWaves * T - 1) / (kWgWaves * T);
     a.n_subjects = (uint32_t)db->n;
     a.q_begin = q_begin;
     a.q_end = q_end;
@@ -238,7 +251,7 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     const uint64_t grid = n_qblocks * a.n_wg_tiles;
     if (grid > 0x7fffffffull)
         return set_error(SMAFA_ERR_INVALID, "scan grid too large (%llu workgroups)", (unsigned long long)grid);
-    launch_scan(db, qs->qrec.as<uint32_t>(), a, (uint32_t)grid);
+    launch_scan(db, qs->qrec.as<uint32_t>(), a, (uint32_t)grid, T);
     HIP_TRY(hipGetLastError());
     db->last_launches++;
     return SMAFA_OK;
@@ -470,6 +483,7 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     db->W = (seq_len + 31) / 32;
     db->QS = (uint32_t)qrec_stride((int)db->PQ, (int)db->W);
     if (const char *fv = getenv("SMAFA_FILTER")) db->use_filter = atoi(fv) != 0;
+    if (const char *tv = getenv("SMAFA_TILES")) db->tiles_override = atoi(tv) == 2 ? 2u : atoi(tv) == 1 ? 1u : 0u;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) db->n_cu = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&db->own_stream, hipStreamNonBlocking);

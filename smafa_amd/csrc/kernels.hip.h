@@ -42,19 +42,15 @@ namespace smafa {
 constexpr int kWaveTile = 256;  // subjects per wave tile
 constexpr int kWgWaves = 4;     // waves per workgroup
 constexpr int kChunk = 64;      // queries staged in LDS at a time
-#ifndef SMAFA_GROUP
-#define SMAFA_GROUP 1  // queries per fast-path step (one compare + branch per group); 1 measured best, profiles/r01_variant_matrix.txt
-#endif
-#ifndef SMAFA_MIN_WAVES
-#define SMAFA_MIN_WAVES 6  // __launch_bounds__ second argument: waves per SIMD the register budget must allow
-#endif
-#ifndef SMAFA_VADDR
-#define SMAFA_VADDR 1  // 1: fast-path LDS record address kept in a VGPR (saves a slow-class v_mov per query)
-#endif
+// __launch_bounds__ second argument (waves per SIMD the register budget must allow) for the scan kernel:
+// the subject words held per lane plus ~40 working registers, mapped through the gfx950 allocation steps.
+__host__ __device__ constexpr int scan_min_waves(int ps, int w, int t) {
+    const int regs = t * ps * w * 4 + 40;
+    return regs <= 64 ? 8 : regs <= 80 ? 6 : regs <= 96 ? 5 : regs <= 128 ? 4 : regs <= 168 ? 3 : 2;
+}
 #ifndef SMAFA_AND_PAIR
 #define SMAFA_AND_PAIR 1  // 1: the prefilter bounds two subjects with one popcount (weaker, cheaper: +5 % measured)
 #endif
-constexpr int kGroup = SMAFA_GROUP;
 
 __host__ __device__ constexpr int round_up4(int x) { return (x + 3) & ~3; }
 // query record stride in u32 words: the plane words plus the bound slot, rounded up to whole uint4s
@@ -70,7 +66,7 @@ __host__ __device__ constexpr int bound_slot(int words) { return words; }
 
 struct ScanArgs {
     uint32_t tile_begin, tile_end;  // wave-tile range of this launch
-    uint32_t n_wg_tiles;            // ceil((tile_end - tile_begin) / 4)
+    uint32_t n_wg_tiles;            // ceil((tile_end - tile_begin) / (4 * tiles per wave))
     uint32_t n_subjects;
     uint32_t q_begin, q_end;  // query range of this launch
     uint32_t qb_size;         // queries per workgroup pass
@@ -144,9 +140,12 @@ __device__ __forceinline__ void emit(const ScanArgs &a, uint32_t q, uint32_t sub
 // ---------------------------------------------------------------------------------------------
 // PS = planes stored per subject, PQ = planes per query record (PS < PQ only for the N-free nucleotide
 // store: subjects carry code bits 0-1, queries still carry the N bit, which mismatches every subject).
-template <int PS, int PQ, int W, bool SEED>
-__global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 *__restrict__ planes,
-                                                   const uint32_t *__restrict__ qrec, ScanArgs a) {
+// T = wave tiles per wave: a lane owns 4*T subjects, so the per-query OR / compare / branch / LDS read are
+// shared by 4*T pairs.  T = 2 where the registers allow it without losing occupancy.
+template <int PS, int PQ, int W, int T, bool SEED>
+__global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(const uint4 *__restrict__ planes,
+                                                                             const uint32_t *__restrict__ qrec,
+                                                                             ScanArgs a) {
     constexpr int RS = qrec_stride(PQ, W);  // words per record
     constexpr int RV = RS / 4;              // uint4 per record
     constexpr int NV = (kChunk * RV + 255) / 256;
@@ -161,16 +160,18 @@ __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 
     const uint32_t wave = tid >> 6;
     const uint32_t wg_tile = blockIdx.x % a.n_wg_tiles;  // tiles fastest: all CUs share one query block
     const uint32_t qblock = blockIdx.x / a.n_wg_tiles;
-    const uint32_t tile = a.tile_begin + wg_tile * kWgWaves + wave;
-    const bool active = tile < a.tile_end;  // idle waves still take part in staging and barriers
+    const uint32_t tile0 = a.tile_begin + (wg_tile * kWgWaves + wave) * T;  // this wave's first tile
+    // waves (and trailing tiles of a wave) past the range still take part in staging and barriers
 
-    uint4 s[PS * W];
-    {
-        const uint4 *t = planes + (size_t)(active ? tile : a.tile_begin) * (PS * W * 64) + lane;
+    uint4 s[T][PS * W];
 #pragma unroll
-        for (int i = 0; i < PS * W; i++) s[i] = t[i * 64];
+    for (int t = 0; t < T; t++) {
+        const bool live = tile0 + t < a.tile_end;
+        const uint4 *src = planes + (size_t)(live ? tile0 + t : a.tile_begin) * (PS * W * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < PS * W; i++) s[t][i] = src[i * 64];
     }
-    const uint32_t subj0 = tile * kWaveTile + lane * 4u;
+    const bool active = tile0 < a.tile_end;
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
     const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
 
@@ -200,51 +201,56 @@ __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 
         for (int v = 0; v < NV; v++) {
             const uint32_t idx = tid + v * 256;
             if (idx < nqc * RV) stage[buf][idx] = pre[v];
-            else if (idx < (nqc + kGroup - 1) / kGroup * kGroup * RV)
-                stage[buf][idx] = make_uint4(0, 0, 0, 0);  // never-pass padding up to a whole group
         }
     };
 
-    // full comparison of one query against this lane's 4 subjects; qw = the whole record
+    // full comparison of one query against this lane's 4*T subjects; qw = the whole record
     auto full_compare = [&](const uint32_t(&qw)[RS], uint32_t q) {
         const uint32_t U = ~qw[BS];
-        uint32_t d[4];
+        uint32_t lo = 0xffffffffu;  // SEED only
 #pragma unroll
-        for (int w = 0; w < W; w++) {
-            uint32_t extra = 0;  // query bits in planes no subject has: a mismatch against every subject
+        for (int t = 0; t < T; t++) {
+            uint32_t d[4];
 #pragma unroll
-            for (int p = PS; p < PQ; p++) extra |= qw[qslot(PQ, W, p, w)];
-            uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
+            for (int w = 0; w < W; w++) {
+                uint32_t extra = 0;  // query bits in planes no subject has: a mismatch against every subject
 #pragma unroll
-            for (int p = 0; p < PS; p++) {
-                const uint4 v = s[p * W + w];
-                const uint32_t qv = qw[qslot(PQ, W, p, w)];
-                const bool first = p == 0 && PS == PQ;
-                m0 = first ? (v.x ^ qv) : or_xor(m0, v.x, qv);
-                m1 = first ? (v.y ^ qv) : or_xor(m1, v.y, qv);
-                m2 = first ? (v.z ^ qv) : or_xor(m2, v.z, qv);
-                m3 = first ? (v.w ^ qv) : or_xor(m3, v.w, qv);
+                for (int p = PS; p < PQ; p++) extra |= qw[qslot(PQ, W, p, w)];
+                uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
+#pragma unroll
+                for (int p = 0; p < PS; p++) {
+                    const uint4 v = s[t][p * W + w];
+                    const uint32_t qv = qw[qslot(PQ, W, p, w)];
+                    const bool first = p == 0 && PS == PQ;
+                    m0 = first ? (v.x ^ qv) : or_xor(m0, v.x, qv);
+                    m1 = first ? (v.y ^ qv) : or_xor(m1, v.y, qv);
+                    m2 = first ? (v.z ^ qv) : or_xor(m2, v.z, qv);
+                    m3 = first ? (v.w ^ qv) : or_xor(m3, v.w, qv);
+                }
+                d[0] = (w ? d[0] : 0u) + __builtin_popcount(m0);
+                d[1] = (w ? d[1] : 0u) + __builtin_popcount(m1);
+                d[2] = (w ? d[2] : 0u) + __builtin_popcount(m2);
+                d[3] = (w ? d[3] : 0u) + __builtin_popcount(m3);
             }
-            d[0] = (w ? d[0] : 0u) + __builtin_popcount(m0);
-            d[1] = (w ? d[1] : 0u) + __builtin_popcount(m1);
-            d[2] = (w ? d[2] : 0u) + __builtin_popcount(m2);
-            d[3] = (w ? d[3] : 0u) + __builtin_popcount(m3);
+            const uint32_t subj0 = (tile0 + t) * kWaveTile + lane * 4u;
+            const bool live = tile0 + t < a.tile_end;  // a trailing tile slot holds a copy of another tile: ignore it
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool real = live && subj0 + k < a.n_subjects;
+                if (SEED) {
+                    if (real) lo = min(lo, d[k]);
+                } else if (real && d[k] <= U) {
+                    emit(a, q, subj0 + k, d[k]);
+                }
+            }
         }
         if (SEED) {
-            // seed pass for the running minimum (its own instantiation: keeps this code out of the hot kernel,
-            // where it cost 3.5 % through register allocation alone): one atomicMin per wave instead of one per qualifying pair
-            uint32_t lo = 0xffffffffu;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (subj0 + k < a.n_subjects) lo = min(lo, d[k]);
+            // seed pass for the running minimum (its own instantiation: this code in the hot kernel cost 3.5 %
+            // through register allocation alone): one atomicMin per wave instead of one per qualifying pair
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
             if (lane == 0 && lo < U) atomicMin(a.thr + q, lo);
-            return;
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, q, subj0 + k, d[k]);
     };
     auto read_record = [&](const uint4 *rec, uint32_t(&qw)[RS], int from, int to) {
 #pragma unroll
@@ -274,86 +280,38 @@ __global__ __launch_bounds__(256, SMAFA_MIN_WAVES) void scan_kernel(const uint4 
             const bool probe = a.use_filter && (filter_on || (chunk_no & 15u) == 0);
             if (probe) {
                 uint32_t passes = 0;  // wave-uniform: queries of this chunk that needed the full comparison
-                // kGroup queries per step: their sign words are OR-ed into one, so the common case costs one
-                // compare + one branch per group.  Records past nqc are zero (bound slot 0 => never pass).
-#if SMAFA_VADDR
-                // The record address lives in a VGPR and advances with an all-VGPR add: hipcc would otherwise keep
-                // it scalar and pay one v_mov s->v (slow issue class) per query for the ds_read address.
-                uint32_t voff = (uint32_t)buf * (kChunk * RV * 16u), vstep = kGroup * RV * 16u;
-                asm volatile("" : "+v"(voff), "+v"(vstep));
-#endif
-                for (uint32_t i = 0; i < nqc; i += kGroup, rec += kGroup * RV) {
-                    uint32_t head[kGroup][4 * HV];
-                    uint32_t any[kGroup];
-#if SMAFA_VADDR
-                    const uint4 *hrec = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(&stage[0][0]) + voff);
-                    voff += vstep;
-#else
-                    const uint4 *hrec = rec;
-#endif
+                for (uint32_t i = 0; i < nqc; i++, rec += RV) {
+                    uint32_t qw[RS];
+                    read_record(rec, qw, 0, HV);  // fast path: filter-plane words + bound slot only
+                    const uint32_t nu = qw[BS];
+                    uint32_t any = 0;
 #pragma unroll
-                    for (int j = 0; j < kGroup; j++) {
-#pragma unroll
-                        for (int v = 0; v < HV; v++) {
-                            const uint4 x = hrec[j * RV + v];
-                            head[j][4 * v + 0] = x.x;
-                            head[j][4 * v + 1] = x.y;
-                            head[j][4 * v + 2] = x.z;
-                            head[j][4 * v + 3] = x.w;
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < kGroup; j++) {
+                    for (int t = 0; t < T; t++) {
                         // lower bound on the filter plane, folded over the words
-                        uint32_t m0 = s[FP * W].x ^ head[j][0], m1 = s[FP * W].y ^ head[j][0];
-                        uint32_t m2 = s[FP * W].z ^ head[j][0], m3 = s[FP * W].w ^ head[j][0];
+                        uint32_t m0 = s[t][FP * W].x ^ qw[0], m1 = s[t][FP * W].y ^ qw[0];
+                        uint32_t m2 = s[t][FP * W].z ^ qw[0], m3 = s[t][FP * W].w ^ qw[0];
 #pragma unroll
                         for (int w = 1; w < W; w++) {
-                            m0 = or_xor(m0, s[FP * W + w].x, head[j][w]);
-                            m1 = or_xor(m1, s[FP * W + w].y, head[j][w]);
-                            m2 = or_xor(m2, s[FP * W + w].z, head[j][w]);
-                            m3 = or_xor(m3, s[FP * W + w].w, head[j][w]);
+                            m0 = or_xor(m0, s[t][FP * W + w].x, qw[w]);
+                            m1 = or_xor(m1, s[t][FP * W + w].y, qw[w]);
+                            m2 = or_xor(m2, s[t][FP * W + w].z, qw[w]);
+                            m3 = or_xor(m3, s[t][FP * W + w].w, qw[w]);
                         }
-                        const uint32_t nu = head[j][BS];
 #if SMAFA_AND_PAIR
                         // popcount(a & b) <= min(popcount a, popcount b): one popcount bounds two subjects
                         const uint32_t t0 = __builtin_popcount(m0 & m1) + nu, t2 = __builtin_popcount(m2 & m3) + nu;
-                        any[j] = j ? or3(t0, t2, any[j - 1]) : (t0 | t2);
+                        any = t ? or3(any, t0, t2) : (t0 | t2);
 #else
                         const uint32_t t0 = __builtin_popcount(m0) + nu, t1 = __builtin_popcount(m1) + nu;
                         const uint32_t t2 = __builtin_popcount(m2) + nu, t3 = __builtin_popcount(m3) + nu;
-                        any[j] = j ? or3(or3(t0, t1, t2), t3, any[j - 1]) : (or3(t0, t1, t2) | t3);  // running OR
+                        any = t ? or3(or3(t0, t1, t2), t3, any) : (or3(t0, t1, t2) | t3);
 #endif
                     }
-                    if (__ballot((int32_t)any[kGroup - 1] < 0) != 0ull) {  // wave-uniform, rare
-#pragma unroll
-                        for (int j = 0; j < kGroup; j++) {
-                            // any[j] is cumulative; query j itself passed iff its own bits did: recompute cheaply
-                            uint32_t qw[RS];
-#pragma unroll
-                            for (int v = 0; v < 4 * HV; v++) qw[v] = head[j][v];
-                            uint32_t m0 = s[FP * W].x ^ qw[0], m1 = s[FP * W].y ^ qw[0];
-                            uint32_t m2 = s[FP * W].z ^ qw[0], m3 = s[FP * W].w ^ qw[0];
-#pragma unroll
-                            for (int w = 1; w < W; w++) {
-                                m0 = or_xor(m0, s[FP * W + w].x, qw[w]);
-                                m1 = or_xor(m1, s[FP * W + w].y, qw[w]);
-                                m2 = or_xor(m2, s[FP * W + w].z, qw[w]);
-                                m3 = or_xor(m3, s[FP * W + w].w, qw[w]);
-                            }
-                            const uint32_t nu = qw[BS];
-#if SMAFA_AND_PAIR
-                            const uint32_t own = (__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu);
-#else
-                            const uint32_t own = or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
-                                                     __builtin_popcount(m2) + nu) | (__builtin_popcount(m3) + nu);
-#endif
-                            if (i + j < nqc && __ballot((int32_t)own < 0) != 0ull) {
-                                passes++;
-                                read_record(rec + j * RV, qw, HV, RV);
-                                full_compare(qw, qc + i + j);
-                            }
-                        }
+                    // sign bit set <=> some lower bound <= bound
+                    if (__ballot((int32_t)any < 0) != 0ull) {  // wave-uniform branch, rare
+                        passes++;
+                        read_record(rec, qw, HV, RV);
+                        full_compare(qw, qc + i);
                     }
                 }
                 filter_on = passes * 4u <= nqc;

@@ -1,21 +1,24 @@
 #!/bin/bash
-# Build the library with different kernel tuning macros and bench each (run on the GPU box).
+# A/B of scan-kernel variants on the GPU box.  Run-time knobs (no rebuild): SMAFA_TILES=1|2 (wave tiles per
+# wave), SMAFA_FILTER=0|1, SMAFA_NT_PLANES=3.  Build-time knobs go through EXTRA (e.g. -DSMAFA_AND_PAIR=0).
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-CONFIGS="${CONFIGS:-1,4 1,6 2,4 2,6 4,4 4,5 4,6 8,4}"
-for cfg in $CONFIGS; do
-  g=${cfg%,*}; w=${cfg#*,}
-  make -C smafa_amd/csrc -B -j8 EXTRA_HIPFLAGS="-DSMAFA_GROUP=$g -DSMAFA_MIN_WAVES=$w ${EXTRA:-}" > /dev/null 2>&1 || { echo "build failed $cfg"; continue; }
-  timeout -k 10 120 python bench.py --steps 10 --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-} > gpurun_out/var_${g}_${w}.json 2> gpurun_out/var_${g}_${w}.err
-  python - "$g" "$w" <<'PY'
+if [ -n "${EXTRA:-}" ]; then make -C smafa_amd/csrc -B -j8 EXTRA_HIPFLAGS="$EXTRA" > /dev/null 2>&1 || { echo "build failed"; exit 1; }; fi
+for alpha in ${ALPHABETS:-aa nt}; do
+  for tiles in ${TILES:-1 2}; do
+    for rep in 1 2; do
+      if [ "$alpha" = nt ]; then args="--alphabet nt --max-div 3 --queries 100000"; else args=""; fi
+      SMAFA_TILES=$tiles timeout -k 10 150 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-stream $args ${BENCH_ARGS:-} > gpurun_out/var.json 2> gpurun_out/var.err
+      python - "$alpha" "$tiles" <<'PY'
 import json,sys
-g,w=sys.argv[1],sys.argv[2]
 try:
-    d=json.load(open(f"gpurun_out/var_{g}_{w}.json"))
-    print(f"group={g} minwaves={w}  q/s={d['value']:.0f}  kernel_ms={d['roofline']['kernel_ms_avg']:.3f} verified={d['verified']}")
+    d=json.load(open("gpurun_out/var.json"))
+    print(f"{sys.argv[1]} tiles/wave={sys.argv[2]}  q/s={d['value']:.0f}  kernel_ms={d['roofline']['kernel_ms_avg']:.3f} verified={d['verified']} B/subject={d['roofline']['stored_bytes_per_subject']}")
 except Exception as e:
-    print(f"group={g} minwaves={w} FAILED {e}")
+    print(f"{sys.argv[1]} tiles={sys.argv[2]} FAILED {e}")
 PY
+    done
+  done
 done
-make -C smafa_amd/csrc -B -j8 > /dev/null 2>&1
+if [ -n "${EXTRA:-}" ]; then make -C smafa_amd/csrc -B -j8 > /dev/null 2>&1; fi
