@@ -231,9 +231,9 @@ def main() -> None:
         filt = os.environ.get("SMAFA_FILTER", "1") != "0"
         W_, P_ = info.words_per_plane, info.planes
         # VALU wave-instructions per (query, subject) pair = lane-ops per pair.  Prefilter fast path, per lane and
-        # query: 4 subjects x (W xor/bitop3 + 1 popcount) + or3 + or + compare + LDS address = 4(W+1) + 4.
-        # Full comparison: 4 subjects x (P*W xor/bitop3 + W popcounts) + 4 compares.
-        ops_per_pair = (W_ + 2.0) if filt else (P_ * W_ + W_ + 1.0)
+        # query: 4 subjects x W xor/bitop3 + 2 and + 2 popcounts (one per two subjects) + or + compare + LDS
+        # address add = 4W + 7 per 4 pairs.  Full comparison: 4 subjects x (P*W xor/bitop3 + W popcounts) + 4 compares.
+        ops_per_pair = (W_ + 1.75) if filt else (P_ * W_ + W_ + 1.0)
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc_path) and (N, L, Q, D, args.alphabet) == (10_000_000, 60, 10_000, 5, "aa"):
