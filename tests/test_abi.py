@@ -187,3 +187,16 @@ def test_synth_queries_have_planted_distance():
         q, rows, subs = synth.queries(s, 200, alphabet, seed=3, max_subs=ms)
         d = (s[rows] != q).sum(axis=1)
         assert (d == subs).all()
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """what a C or Rust host does: include the header as C99, link the shared object, call the ABI"""
+    exe = tmp_path / "abi_c_check"
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "abi_c_check.c"), "-o", str(exe), "-L", lib_dir, "-lsmafa_amd",
+                        "-Wl,-rpath," + lib_dir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe), str(tmp_path / "t.db")], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "abi ok" in r.stdout

@@ -414,3 +414,58 @@ def test_nt_two_plane_store_other_lengths(L):
     for D in (1, 4):
         assert store.scan(q, max_divergence=D).tobytes() == oracle.scan_codes(s, q, D).tobytes()
     store.close()
+
+
+# ------------------------------------------------------------------- CLI edge cases vs the oracle CLI
+def both_cli(*args):
+    got = cli(*args)
+    want = oracle.run_cli(*args)
+    return got, want
+
+
+def test_cli_edge_cases_match_oracle(tmp_path):
+    import gzip
+
+    d = tmp_path
+    # multi-line FASTA with CRLF, lowercase and IUPAC letters, '-' gaps; last record without trailing newline
+    (d / "s.fna").write_bytes(b">s0 first\r\nACGTAC\r\nGTAC\r\n>s1\nacgtrygtac\n>s2\nAC-TACGTAN\n>s3\nTTTTTTTTTT\n>s4 dup of s0\nACGTACGTAC")
+    # gzip FASTQ queries
+    with gzip.open(d / "q.fq.gz", "wb") as f:
+        f.write(b"@q0\nACGTACGTAC\n+\nIIIIIIIIII\n@q1\nACGTNNGTAC\n+\nIIIIIIIIII\n@q2\nTTTTTTTTTA\n+\nIIIIIIIIII\n")
+    db = str(d / "db")
+    assert cli("makedb", "-i", str(d / "s.fna"), "-d", db).returncode == 0
+    db2 = str(d / "db2")
+    assert oracle.run_cli("makedb", "-i", str(d / "s.fna"), "-d", db2).returncode == 0
+    assert open(db, "rb").read() == open(db2, "rb").read()
+    for flags in ([], ["--max-divergence", "1"], ["--max-num-hits", "3"], ["--max-num-hits", "2", "--limit-per-sequence", "1"],
+                  ["--max-divergence", "0"], ["--max-num-hits", "100"]):
+        got, want = both_cli("query", "-d", db, "-q", str(d / "q.fq.gz"), *flags)
+        assert got.returncode == want.returncode == 0, (flags, got.stderr, want.stderr)
+        assert got.stdout == want.stdout, flags
+    # a store with zero windows: the reference unwraps the min/max of an empty vector (src/lib.rs:254,298)
+    smafa_amd.write_db(str(d / "empty.db"), np.zeros((0, 10), dtype=np.uint8))
+    for flags in ([], ["--max-num-hits", "5"]):
+        got, want = both_cli("query", "-d", str(d / "empty.db"), "-q", str(d / "q.fq.gz"), *flags)
+        assert got.returncode == want.returncode == 101 and got.stdout == want.stdout == ""
+        assert "Option::unwrap()" in got.stderr
+    # an empty record among the queries: length mismatch after the rows of the earlier queries
+    (d / "q2.fna").write_bytes(b">a\nACGTACGTAC\n>empty\n\n>c\nACGTACGTAC\n")
+    got, want = both_cli("query", "-d", db, "-q", str(d / "q2.fna"))
+    assert got.returncode == want.returncode == 101 and got.stdout == want.stdout and got.stdout.startswith("0\t0\t0\t")
+    assert "Cannot compute distances between seq of length 0 and windows of lengths 10" in got.stderr
+    # single-subject store, k larger than the store, max-num-hits 0 (index underflow in the reference)
+    (d / "one.fna").write_bytes(b">only\nACGTACGTAC\n")
+    assert cli("makedb", "-i", str(d / "one.fna"), "-d", str(d / "one.db")).returncode == 0
+    got, want = both_cli("query", "-d", str(d / "one.db"), "-q", str(d / "q.fq.gz"), "--max-num-hits", "7")
+    assert got.returncode == 0 and got.stdout == want.stdout
+    got, want = both_cli("query", "-d", str(d / "one.db"), "-q", str(d / "q.fq.gz"), "--max-num-hits", "0")
+    assert got.returncode == want.returncode == 101 and "index out of bounds" in got.stderr
+    # cluster: duplicates differing only by case / IUPAC class collapse to one record; raw bytes echoed
+    (d / "c.fna").write_bytes(b">1\nACGTACGTAC\n>2\nacgtacgtac\n>3\nACGTACGTAR\n>4\nACGTACGTAY\n>5\nTTTTTTTTTT\n")
+    for D in ("0", "1"):
+        got, want = both_cli("cluster", "-i", str(d / "c.fna"), "-d", D)
+        assert got.returncode == want.returncode == 0 and got.stdout == want.stdout, D
+    # cluster: ragged input fails after the lines already due
+    (d / "c2.fna").write_bytes(b">1\nACGTACGTAC\n>2\nACGTACGTAA\n>3\nACGT\n>4\nACGTACGTAC\n")
+    got, want = both_cli("cluster", "-i", str(d / "c2.fna"), "-d", "1")
+    assert got.returncode == want.returncode == 101 and got.stdout == want.stdout and got.stdout.count("\n") == 2
