@@ -442,12 +442,14 @@ def test_cli_edge_cases_match_oracle(tmp_path):
         got, want = both_cli("query", "-d", db, "-q", str(d / "q.fq.gz"), *flags)
         assert got.returncode == want.returncode == 0, (flags, got.stderr, want.stderr)
         assert got.stdout == want.stdout, flags
-    # a store with zero windows: the reference unwraps the min/max of an empty vector (src/lib.rs:254,298)
+    # a store with zero windows serialises to 3 bytes (02 00 00), and the reference slices &buffer[0..4]
+    # before anything else (src/lib.rs:214): that panic, not the empty-vector unwrap, is what a user sees
     smafa_amd.write_db(str(d / "empty.db"), np.zeros((0, 10), dtype=np.uint8))
+    assert open(d / "empty.db", "rb").read() == bytes([2, 0, 0])
     for flags in ([], ["--max-num-hits", "5"]):
         got, want = both_cli("query", "-d", str(d / "empty.db"), "-q", str(d / "q.fq.gz"), *flags)
         assert got.returncode == want.returncode == 101 and got.stdout == want.stdout == ""
-        assert "Option::unwrap()" in got.stderr
+        assert "range end index 4 out of range for slice of length 3" in got.stderr
     # an empty record among the queries: length mismatch after the rows of the earlier queries
     (d / "q2.fna").write_bytes(b">a\nACGTACGTAC\n>empty\n\n>c\nACGTACGTAC\n")
     got, want = both_cli("query", "-d", db, "-q", str(d / "q2.fna"))
