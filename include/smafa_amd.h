@@ -66,6 +66,10 @@ typedef struct {
 /* ------------------------------------------------------------------ library */
 const char *smafa_last_error(void);
 int smafa_device_count(void); /* 0 when no MI355X is visible; never fails */
+/* Progress / timing lines of the drivers on stderr (the reference logs through env_logger, src/lib.rs:206,230,
+ * 320-323; src/cluster.rs:33,87-92): 0 = errors only (--quiet), 1 = info (default of the reference), 2 = debug (-v).
+ * The library default is 0 so that stderr stays clean for hosts that do not ask. */
+void smafa_set_verbosity(int level);
 
 /* ----------------------------------------------------------------- encoding */
 /* Replaces create_lut/BYTE_LUT/encode_single (src/lib.rs:167-196) and the per-byte half of

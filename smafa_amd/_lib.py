@@ -22,7 +22,7 @@ ALPHABET_NT, ALPHABET_AA = 0, 1
 
 # every symbol include/smafa_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "smafa_last_error", "smafa_device_count", "smafa_encode", "smafa_decode",
+    "smafa_last_error", "smafa_device_count", "smafa_set_verbosity", "smafa_encode", "smafa_decode",
     "smafa_db_create", "smafa_db_append", "smafa_db_info", "smafa_db_set_stream", "smafa_db_destroy",
     "smafa_scan_hits", "smafa_distances", "smafa_qset_create", "smafa_qset_destroy", "smafa_scan_launch",
     "smafa_sync", "smafa_last_scan_ms", "smafa_set_query_block", "smafa_select_rows",
@@ -69,6 +69,8 @@ def lib() -> C.CDLL:
     u8p, u32p, u64p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p
     l.smafa_last_error.restype = C.c_char_p
     l.smafa_device_count.restype = C.c_int
+    l.smafa_set_verbosity.argtypes = [C.c_int]
+    l.smafa_set_verbosity.restype = None
     l.smafa_encode.argtypes = [C.c_int, vp, C.c_uint64, vp, u64p]
     l.smafa_decode.argtypes = [C.c_int, vp, C.c_uint64, vp]
     l.smafa_db_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_uint32]

@@ -23,6 +23,11 @@ int select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint
                 const uint8_t *subject_codes, uint32_t seq_len, uint32_t max_div, uint32_t max_num_hits,
                 uint32_t limit_per_sequence, std::vector<smafa_hit> &rows);
 
+// stderr logging of the drivers (host/common.cpp): level 1 = info, 2 = debug
+int verbosity();
+void log_line(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+double now_seconds();
+
 // alphabet tables (host/alphabet.cpp)
 uint8_t code_of(int alphabet, uint8_t byte);  // 255 = outside the alphabet
 char letter_of(int alphabet, uint8_t code);

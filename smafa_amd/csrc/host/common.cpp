@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 
 #include "../engine.h"
 
@@ -17,9 +18,31 @@ int set_error(int code, const char *fmt, ...) {
     return code;
 }
 
+static int g_verbosity = 0;
+
+int verbosity() { return g_verbosity; }
+
+double now_seconds() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+void log_line(int level, const char *fmt, ...) {
+    if (g_verbosity < level) return;
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "[%s smafa] %s\n", level >= 2 ? "DEBUG" : "INFO", buf);
+}
+
 }  // namespace smafa
 
 extern "C" {
+
+void smafa_set_verbosity(int level) { smafa::g_verbosity = level; }
 
 const char *smafa_last_error(void) { return smafa::g_error; }
 

@@ -195,7 +195,10 @@ int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet) {
     }
     if (rc < 0) return rc;
     if (L > 0xffffffffull) return set_error(SMAFA_ERR_INVALID, "sequence too long");
-    return smafa_dbfile_write(db_path, alphabet, codes.data(), n, (uint32_t)L);  // src/lib.rs:161-162
+    log_line(1, "Encoding of %llu sequences complete, writing db file %s", (unsigned long long)n, db_path);  // src/lib.rs:154-158
+    rc = smafa_dbfile_write(db_path, alphabet, codes.data(), n, (uint32_t)L);  // src/lib.rs:161-162
+    if (rc == SMAFA_OK) log_line(1, "DB file written");
+    return rc;
 }
 
 // -------------------------------------------------------------------------------------- query
@@ -207,9 +210,12 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
     uint32_t L = 0;
     FreeGuard codes_guard;
     uint8_t *codes = nullptr;
+    const double t_start = now_seconds();
+    log_line(1, "Decoding db file \"%s\"", db_path);  // src/lib.rs:206
     int rc = smafa_dbfile_read(db_path, &alphabet, &codes, &n, &L);  // src/lib.rs:208-218
     if (rc) return rc;
     codes_guard.p = codes;
+    log_line(2, "db decoded: %llu sequences of length %u in %.2f s", (unsigned long long)n, L, now_seconds() - t_start);
 
     FastxReader reader;
     rc = reader.open(query_fasta);  // src/lib.rs:221
@@ -217,11 +223,15 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
 
     DbGuard guard;
     if (n > 0) {
+        const double t0 = now_seconds();
         rc = smafa_db_create(&guard.db, device, alphabet, L);
         if (rc) return rc;
         rc = smafa_db_append(guard.db, codes, n);
         if (rc) return rc;
+        log_line(2, "subject store packed into HBM on device %d in %.2f s", device, now_seconds() - t0);
     }
+    log_line(1, "Querying ..");  // src/lib.rs:230
+    double t_scan = 0, t_select = 0;
 
     const bool kmode = max_num_hits != SMAFA_NONE && max_num_hits != 1;  // src/lib.rs:224
     // the device bound: k-th smallest distance (k = 1: the minimum); no k bound when k exceeds the store
@@ -241,13 +251,17 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
     auto flush = [&]() -> int {
         if (in_chunk == 0) return SMAFA_OK;
         hits.clear();
+        double t0 = now_seconds();
         if (n > 0) {
             int r = scan_to_host(guard.db, qcodes.data(), in_chunk, max_divergence, dev_k, hits);
             if (r) return r;
         }
+        t_scan += now_seconds() - t0;
+        t0 = now_seconds();
         int r = select_rows(hits.data(), hits.size(), in_chunk, n, codes, L, max_divergence, max_num_hits,
                             limit_per_sequence, rows);
         if (r) return r;
+        t_select += now_seconds() - t0;
         text.clear();
         const uint32_t q_base = query_number - (uint32_t)in_chunk;
         for (const smafa_hit &h : rows) {
@@ -297,6 +311,8 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
     int frc = flush();
     if (frc) return frc;
     if (pending != SMAFA_OK) return set_error(pending, "%s", pending_msg.c_str());
+    log_line(2, "%u queries: scans %.2f s, selection %.2f s", query_number, t_scan, t_select);
+    log_line(1, "Querying complete, took %llu seconds", (unsigned long long)(now_seconds() - t_start));  // src/lib.rs:320-323
     return SMAFA_OK;
 }
 
@@ -320,9 +336,11 @@ int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, 
     if (!input_fasta) return set_error(SMAFA_ERR_INVALID, "smafa_cluster: NULL path");
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
+    const double t_start = now_seconds();
     FastxReader reader;
     int rc = reader.open(input_fasta);  // src/cluster.rs:28
     if (rc) return rc;
+    log_line(1, "Clustering ..");  // src/cluster.rs:33
 
     std::vector<uint8_t> raw, codes;
     uint64_t n = 0;
@@ -477,6 +495,8 @@ int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, 
         }
         rc = write_all(out_fd, text.data(), text.size());
         if (rc) return rc;
+        log_line(1, "Clustering complete, took %llu seconds. Clustered %llu sequences into %zu clusters.",  // src/cluster.rs:87-92
+                 (unsigned long long)(now_seconds() - t_start), (unsigned long long)n, centroid_rec.size());
     }
     if (pending != SMAFA_OK) return set_error(pending, "%s", pending_msg.c_str());
     return SMAFA_OK;

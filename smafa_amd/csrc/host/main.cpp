@@ -57,6 +57,8 @@ int main(int argc, char **argv) {
     uint32_t max_div = SMAFA_NONE, max_hits = SMAFA_NONE, limit = SMAFA_NONE, device = 0;
     bool have_max_div = false;
     int alphabet = SMAFA_ALPHABET_NT;
+    int verbosity = 1;  // the reference logs at info level unless told otherwise (bird_tool_utils set_log_level)
+    if (const char *e = getenv("SMAFA_LOG")) verbosity = atoi(e);
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         auto value = [&]() -> const char * { return i + 1 < argc ? argv[++i] : nullptr; };
@@ -74,7 +76,9 @@ int main(int argc, char **argv) {
         } else if (a == "-q" || a == "--query") {
             if (cmd == "query") {
                 if (!(query = value())) return usage("--query needs a value");
-            }  // elsewhere -q is --quiet
+            } else {
+                verbosity = 0;  // elsewhere -q is --quiet
+            }
         } else if (a == "--max-num-hits") {
             if (!parse_u32(value(), &max_hits)) return usage("--max-num-hits needs an unsigned integer");
         } else if (a == "--limit-per-sequence") {
@@ -86,8 +90,10 @@ int main(int argc, char **argv) {
             if (v && !strcmp(v, "nt")) alphabet = SMAFA_ALPHABET_NT;
             else if (v && !strcmp(v, "aa")) alphabet = SMAFA_ALPHABET_AA;
             else return usage("--alphabet is nt or aa");
-        } else if (a == "-v" || a == "--verbose" || a == "--quiet") {
-            // logging flags of bird_tool_utils: stderr only, nothing to change here
+        } else if (a == "-v" || a == "--verbose") {
+            verbosity = 2;  // debug
+        } else if (a == "--quiet") {
+            verbosity = 0;  // errors only
         } else if (a == "-h" || a == "--help") {
             usage(nullptr);
             return 0;
@@ -95,6 +101,7 @@ int main(int argc, char **argv) {
             return usage(("unexpected argument " + a).c_str());
         }
     }
+    smafa_set_verbosity(verbosity);
     int rc;
     if (cmd == "makedb") {
         if (!input || !database) return usage("makedb needs --input and --database");
