@@ -2,7 +2,8 @@
 //
 // What the reference does per (query, subject) pair is XOR + popcount over a 5-bit one-hot
 // code, halved (WindowSet::get_distances, /root/reference/src/lib.rs:71-89).  Here a symbol is
-// a b-bit CODE (b = 3 planes for ACGTN, 5 for the amino-acid extension) stored as BIT-PLANES:
+// a b-bit CODE (3 bits for ACGTN — 2 stored planes while no subject holds an N — and 5 for the amino-acid
+// extension) stored as BIT-PLANES:
 // plane p of a subject is the bitset over columns of bit p of each column's code.  Then
 //
 //     mismatch_mask = OR_p ( S_p XOR Q_p )        distance = popcount(mismatch_mask)
