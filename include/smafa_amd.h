@@ -132,6 +132,9 @@ int smafa_sync(smafa_db *db);
 int smafa_last_scan_ms(smafa_db *db, float *ms, uint32_t *n_launches);
 /* Tuning knob: queries per workgroup pass (0 = automatic). */
 int smafa_set_query_block(smafa_db *db, uint32_t queries_per_block);
+/* 1 (default): the scan evaluates an exact lower bound first and runs the full comparison only where it can
+ * still qualify; 0: every (query, subject) pair gets the full comparison.  Results are identical either way. */
+int smafa_set_prefilter(smafa_db *db, int enabled);
 
 /* -------------------------------------------------------- host-side selection */
 /*

@@ -134,6 +134,9 @@ class SubjectStore:
     def set_query_block(self, n: int) -> None:
         check(lib().smafa_set_query_block(self._h, n))
 
+    def set_prefilter(self, enabled: bool) -> None:
+        check(lib().smafa_set_prefilter(self._h, 1 if enabled else 0))
+
     def scan_launch(self, qset: QuerySet, max_divergence: Optional[int], max_num_hits: Optional[int],
                     d_hits: int, cap: int, d_count: int) -> None:
         check(lib().smafa_scan_launch(self._h, qset._h, _opt(max_divergence), _opt(max_num_hits),

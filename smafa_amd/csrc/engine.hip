@@ -558,6 +558,12 @@ int smafa_set_query_block(smafa_db *db, uint32_t queries_per_block) {
     return SMAFA_OK;
 }
 
+int smafa_set_prefilter(smafa_db *db, int enabled) {
+    if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_set_prefilter: NULL handle");
+    db->use_filter = enabled != 0;
+    return SMAFA_OK;
+}
+
 int smafa_qset_create(smafa_qset **out, smafa_db *db, const uint8_t *query_codes, uint64_t n_queries) {
     if (!out || !db || (!query_codes && n_queries)) return set_error(SMAFA_ERR_INVALID, "smafa_qset_create: NULL argument");
     *out = nullptr;
