@@ -92,6 +92,27 @@ def test_query_scan_full_size(n, q, alphabet, D, max_subs, n_frac):
     store.close()
 
 
+def test_query_scan_50m_store_one_rank_share():
+    """configs[3]: 50M x 60 aa store replicated on 8 GPUs, 1M queries sharded — this is ONE rank's share:
+    the whole 50M store (2 GB of bit-planes) and a contiguous block of 125 000 queries"""
+    n, q_total, world, rank, D = 50_000_000, 1_000_000, 8, 3, 5
+    subj = synth.subjects(n, 60, 1, seed=1)
+    rng = np.random.default_rng(17)
+    from smafa_amd import dist as sdist
+    lo, hi = sdist.shard_bounds(q_total, world, rank)
+    assert hi - lo == 125_000
+    # the rank's block of a 1M-query batch: planted queries drawn with the block's own seed
+    qry, planted_row, planted_subs = synth.queries(subj, hi - lo, 1, seed=1000 + rank, max_subs=10)
+    store = smafa_amd.SubjectStore(60, 1)
+    store.push(subj)
+    assert store.info().hbm_bytes == (n + 255) // 256 * 256 * 40
+    rows = store.scan(qry, max_divergence=D)
+    check_rows(rows, subj, qry, D)
+    assert check_planted(rows, planted_row, planted_subs, D) > 60_000
+    sample_vs_oracle(rows, subj, qry, D, rng, k=4)
+    store.close()
+
+
 def rows_as_void(a):
     a = np.ascontiguousarray(a)
     return a.view(np.dtype((np.void, a.shape[1]))).ravel()
