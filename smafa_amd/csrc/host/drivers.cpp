@@ -401,8 +401,12 @@ int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, 
         std::vector<smafa_hit> old_hits, cand_hits;
         std::vector<uint32_t> cand_pos;        // candidate ordinal -> position in the batch
         std::vector<uint32_t> cand_centroid;   // candidate ordinal -> centroid ordinal it became (or NONE)
-        size_t pos = 0, B = 1024;
+        size_t pos = 0, B = 1024, n_batches = 0;
+        double t_old = 0, t_cand = 0, t_seq = 0, t_append = 0;
+        log_line(2, "parsed %llu records (%zu distinct) in %.2f s", (unsigned long long)n, uniq.size(), now_seconds() - t_start);
         while (pos < uniq.size()) {
+            n_batches++;
+            double t0 = now_seconds();
             const size_t nb = std::min(B, uniq.size() - pos);
             batch_codes.resize(nb * L);
             for (size_t b = 0; b < nb; b++) memcpy(&batch_codes[b * L], &codes[(size_t)uniq[pos + b] * L], L);
@@ -413,6 +417,8 @@ int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, 
                 rc = scan_to_host(centroids.db, batch_codes.data(), nb, max_divergence, 1, old_hits);
                 if (rc) return rc;
             }
+            t_old += now_seconds() - t0;
+            t0 = now_seconds();
             std::vector<uint32_t> old_d(nb, UINT32_MAX), old_c(nb, UINT32_MAX);
             for (size_t t = old_hits.size(); t-- > 0;) {  // backwards: the first row of each record wins
                 old_d[old_hits[t].query] = old_hits[t].dist;
@@ -438,6 +444,8 @@ int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, 
                 if (rc) return rc;
             }
 
+            t_cand += now_seconds() - t0;
+            t0 = now_seconds();
             // 3. sequential pass in input order
             cand_centroid.assign(cand_pos.size(), UINT32_MAX);
             new_codes.clear();
@@ -467,10 +475,13 @@ int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, 
                     new_codes.insert(new_codes.end(), &batch_codes[b * L], &batch_codes[b * L] + L);
                 }
             }
+            t_seq += now_seconds() - t0;
+            t0 = now_seconds();
             if (!new_codes.empty()) {
                 rc = smafa_db_append(centroids.db, new_codes.data(), new_codes.size() / L);
                 if (rc) return rc;
             }
+            t_append += now_seconds() - t0;
             pos += nb;
             // batch size follows the row volume: grow while the scans stay cheap, shrink on dense input
             const size_t volume = old_hits.size() + cand_hits.size();
@@ -478,6 +489,8 @@ int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, 
             else if (volume > (16u << 20) && B > 256) B /= 2;
         }
 
+        log_line(2, "%zu batches: scans vs old centroids %.2f s, candidate scans %.2f s, sequential pass %.2f s, "
+                    "centroid appends %.2f s", n_batches, t_old, t_cand, t_seq, t_append);
         // src/cluster.rs:79-84
         std::string text;
         text.reserve(1 << 20);
