@@ -139,6 +139,7 @@ def main() -> None:
 
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     kernel_ms_avg = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    plan = store.last_scan_plan()  # which kernel form the timed launches used
 
     # ---- result check (outside the timed region): planted rows present, every row's distance recomputed
     n_rows = int(d_count.item())
@@ -176,16 +177,20 @@ def main() -> None:
             store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
             k_ms.append(store.last_scan_ms()[0])
         k_med = float(np.median(k_ms))
+        splan = store.last_scan_plan()
+        # bytes one pass streams: the whole block, or only the prefilter's plane when that is all that is resident
+        sb = info.words_per_plane * 4 if splan["filter_plane_resident"] else info.bytes_per_subject
+        streamed = info.hbm_bytes * sb / info.bytes_per_subject
         stream_info = {
             "ms_per_query": ms,
             "kernel_ms_median": k_med,
-            "kernel_stored_GBs": info.hbm_bytes / k_med / 1e6,
-            "kernel_frac_of_peak_stored": info.hbm_bytes / k_med / 1e6 / HBM_PEAK_GBS,
-            "stored_GBs": info.hbm_bytes / ms / 1e6,
-            "algorithmic_GBs": N * L / ms / 1e6,
-            "frac_of_peak_stored": info.hbm_bytes / ms / 1e6 / HBM_PEAK_GBS,
-            "note": "one query per DB pass; stored = bit-plane bytes actually streamed (%d B/subject), "
-                    "algorithmic = %d B/subject" % (info.bytes_per_subject, L),
+            "streamed_bytes_per_subject": int(sb),
+            "kernel_streamed_GBs": streamed / k_med / 1e6,
+            "kernel_frac_of_peak": streamed / k_med / 1e6 / HBM_PEAK_GBS,
+            "kernel_algorithmic_GBs": N * L / k_med / 1e6,
+            "plan": splan,
+            "note": "one query per DB pass; streamed = bit-plane bytes the kernel actually reads per subject (the "
+                    "prefilter's plane only when the other planes are fetched on demand); algorithmic = %d B/subject" % L,
         }
         one.close()
 
@@ -250,6 +255,10 @@ def main() -> None:
         # query: 4 subjects x W xor/bitop3 + 2 and + 2 popcounts (one per two subjects) + or + compare + LDS
         # address add = 4W + 7 per 4 pairs.  Full comparison: 4 subjects x (P*W xor/bitop3 + W popcounts) + 4 compares.
         ops_per_pair = (W_ + 1.75) if filt else (P_ * W_ + W_ + 1.0)
+        if filt and plan["filter_plane_resident"]:
+            # level-1 bound only, 4T subjects per lane: 4T xor + 4T popcounts + 2T or3 + compare + LDS address
+            T_ = plan["tiles_per_wave"]
+            ops_per_pair = (10.0 * T_ + 2.0) / (4.0 * T_)
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc_path) and (N, L, Q, D, args.alphabet) == (10_000_000, 60, 10_000, 5, "aa"):
@@ -298,6 +307,7 @@ def main() -> None:
                         "is VALU issue (see `valu`); the HBM-bound form (one query per pass) is in `stream`." % L,
                 "valu": {
                     "prefilter": filt,
+                    "plan": plan,
                     "lane_ops_per_pair": ops_per_pair,
                     "achieved_lane_ops": pairs_per_launch * ops_per_pair / (kernel_ms_avg * 1e-3),
                     "peak_lane_ops": VALU_PEAK_LANE_OPS,
@@ -307,6 +317,7 @@ def main() -> None:
                             "any op with an SGPR source ~37e12 lane-ops/s",
                 },
                 "stored_bytes_per_subject": int(info.bytes_per_subject),
+                "streamed_bytes_per_subject": int(info.words_per_plane * 4 if plan["filter_plane_resident"] else info.bytes_per_subject),
             },
             "stream": stream_info,
             "unfiltered": unfiltered,

@@ -130,6 +130,10 @@ int smafa_sync(smafa_db *db);
 /* Device time in ms of the scan kernel(s) of the most recent smafa_scan_launch / smafa_scan_hits on
  * this handle, from HIP events recorded on the launch stream; also how many kernel launches it took. */
 int smafa_last_scan_ms(smafa_db *db, float *ms, uint32_t *n_launches);
+/* How the most recent scan kernel launch on this handle was laid out: whether it kept only the prefilter's plane
+ * of each subject resident (then a sparse-hit scan streams words_per_plane*4 bytes per subject instead of
+ * bytes_per_subject), wave tiles per wave, and query blocks (= passes over the store). */
+int smafa_last_scan_plan(smafa_db *db, uint32_t *filter_plane_resident, uint32_t *tiles_per_wave, uint32_t *query_blocks);
 /* Tuning knob: queries per workgroup pass (0 = automatic). */
 int smafa_set_query_block(smafa_db *db, uint32_t queries_per_block);
 /* 1 (default): the scan evaluates an exact lower bound first and runs the full comparison only where it can

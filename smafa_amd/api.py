@@ -150,6 +150,11 @@ class SubjectStore:
         check(lib().smafa_last_scan_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def last_scan_plan(self) -> dict:
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        check(lib().smafa_last_scan_plan(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"filter_plane_resident": bool(a.value), "tiles_per_wave": b.value, "query_blocks": c.value}
+
     def close(self):
         if self._h:
             lib().smafa_db_destroy(self._h)

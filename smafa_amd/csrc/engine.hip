@@ -72,6 +72,9 @@ struct smafa_db {
     uint32_t qb_override = 0;
     bool use_filter = true;  // exact lower-bound prefilter in the scan kernel (SMAFA_FILTER=0 disables)
     uint32_t tiles_override = 0;  // SMAFA_TILES
+    bool lazy = true;             // filter-plane-resident kernel where it applies (SMAFA_LAZY=0 disables)
+    // what the last launch used (smafa_last_scan_plan)
+    uint32_t plan_lazy = 0, plan_tiles = 1, plan_qblocks = 1;
     int n_cu = 256;
     // scratch of the host-buffer API, kept across calls
     DevBuf upload;            // staging for code rows on their way to the pack kernel
@@ -177,6 +180,16 @@ static int qset_fill(smafa_qset *qs, smafa_db *db, const uint8_t *query_codes, u
 }
 
 template <int PS, int PQ, int W, int T>
+static void launch_lazy_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
+    if (a.hits == nullptr && a.k_tight == 1)
+        hipLaunchKernelGGL((scan_lazy_kernel<PS, PQ, W, T, true>), dim3(grid), dim3(256), 0, db->stream,
+                           reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
+    else
+        hipLaunchKernelGGL((scan_lazy_kernel<PS, PQ, W, T, false>), dim3(grid), dim3(256), 0, db->stream,
+                           reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
+}
+
+template <int PS, int PQ, int W, int T>
 static void launch_scan_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
     // the seed pass of the running-minimum mode (no append) has its own instantiation
     if (a.hits == nullptr && a.k_tight == 1)
@@ -187,15 +200,37 @@ static void launch_scan_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
                            reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
 }
 
-// wave tiles per wave (4*T subjects per lane): 2 where the specialisation exists and the extra subject words
-// keep the kernel at >= 6 waves per SIMD; SMAFA_TILES=1|2 overrides (measurements: profiles/)
-static uint32_t tiles_per_wave(const smafa_db *db) {
-    if (db->W > 2) return 1;
-    if (db->tiles_override) return db->tiles_override;
-    return scan_min_waves((int)db->P, (int)db->W, 2) >= 6 ? 2u : 1u;
+// wave tiles per wave (4*T subjects per lane).  With the cheap first-level bound the per-query work that does
+// not depend on the subject count (LDS read, OR tree, compare, branches, loop bookkeeping) is what T amortises:
+// measured 2 beats 1 for every store with W <= 2 even where it costs occupancy (profiles/r01_variant_tiles*.txt).
+// SMAFA_TILES=1|2|4 overrides (4: 2-plane store only).
+// The filter-plane-resident kernel wins where the prefilter prunes (sparse hits: +18 % aa, 5x less HBM traffic)
+// and loses 10-100 % where it cannot — a bound above ~half of the 32 columns level 1 looks at, e.g. best-hit
+// scans without --max-divergence (profiles/r01_lazy_vs_resident.txt).  Chosen per launch from the initial bound.
+constexpr uint32_t kLazyMaxBound = 16;
+static bool use_lazy(const smafa_db *db, uint32_t thr0) {
+    return db->lazy && db->use_filter && db->W == 2 && thr0 <= kLazyMaxBound;
 }
 
-static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid, uint32_t T) {
+static uint32_t tiles_per_wave(const smafa_db *db, bool lazy) {
+    if (lazy) return db->tiles_override == 8 ? 8u : 4u;
+    if (db->W > 2) return 1;
+    if (db->tiles_override == 4) return db->P == 2 ? 4u : 2u;
+    if (db->tiles_override == 1 || db->tiles_override == 2) return db->tiles_override;
+    return 2u;
+}
+
+static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid, uint32_t T,
+                        bool lazy) {
+    if (lazy) {  // filter-plane-resident kernel (L in 33..64)
+#define SMAFA_LAZY(PS_, PQ_, T_)                               \
+    if (db->P == PS_ && db->PQ == PQ_ && T == T_) {            \
+        launch_lazy_t<PS_, PQ_, 2, T_>(db, d_qrec, a, grid);   \
+        return;                                                \
+    }
+        SMAFA_LAZY(2, 3, 4) SMAFA_LAZY(2, 3, 8) SMAFA_LAZY(3, 3, 4) SMAFA_LAZY(3, 3, 8) SMAFA_LAZY(5, 5, 4) SMAFA_LAZY(5, 5, 8)
+#undef SMAFA_LAZY
+    }
 #define SMAFA_CASE(PS_, PQ_, W_, T_)                          \
     if (db->P == PS_ && db->PQ == PQ_ && db->W == W_ && T == T_) { \
         launch_scan_t<PS_, PQ_, W_, T_>(db, d_qrec, a, grid); \
@@ -206,6 +241,7 @@ static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanAr
     SMAFA_CASE(5, 5, 1, 1) SMAFA_CASE(5, 5, 2, 1) SMAFA_CASE(5, 5, 3, 1) SMAFA_CASE(5, 5, 4, 1)
     SMAFA_CASE(2, 3, 1, 2) SMAFA_CASE(2, 3, 2, 2) SMAFA_CASE(3, 3, 1, 2) SMAFA_CASE(3, 3, 2, 2)
     SMAFA_CASE(5, 5, 1, 2) SMAFA_CASE(5, 5, 2, 2)
+    SMAFA_CASE(2, 3, 1, 4) SMAFA_CASE(2, 3, 2, 4)
 #undef SMAFA_CASE
     hipLaunchKernelGGL(scan_generic_kernel, dim3(grid), dim3(256), 0, db->stream,
                        reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a, db->P, db->PQ, db->W, db->QS);
@@ -230,7 +266,8 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
                         unsigned long long *d_count) {
     ScanArgs a;
     const bool specialised = db->W <= 4;  // else scan_generic_kernel: one wave tile per wave
-    const uint32_t T = specialised ? tiles_per_wave(db) : 1u;
+    const bool lazy = specialised && use_lazy(db, thr0);
+    const uint32_t T = specialised ? tiles_per_wave(db, lazy) : 1u;
     a.tile_begin = tile_begin;
     a.tile_end = tile_end;
     a.n_wg_tiles = (tile_end - tile_begin + kWgWaves * T - 1) / (kWgWaves * T);
@@ -251,7 +288,10 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     const uint64_t grid = n_qblocks * a.n_wg_tiles;
     if (grid > 0x7fffffffull)
         return set_error(SMAFA_ERR_INVALID, "scan grid too large (%llu workgroups)", (unsigned long long)grid);
-    launch_scan(db, qs->qrec.as<uint32_t>(), a, (uint32_t)grid, T);
+    launch_scan(db, qs->qrec.as<uint32_t>(), a, (uint32_t)grid, T, lazy);
+    db->plan_lazy = lazy ? 1u : 0u;
+    db->plan_tiles = T;
+    db->plan_qblocks = (uint32_t)n_qblocks;
     HIP_TRY(hipGetLastError());
     db->last_launches++;
     return SMAFA_OK;
@@ -483,7 +523,11 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     db->W = (seq_len + 31) / 32;
     db->QS = (uint32_t)qrec_stride((int)db->PQ, (int)db->W);
     if (const char *fv = getenv("SMAFA_FILTER")) db->use_filter = atoi(fv) != 0;
-    if (const char *tv = getenv("SMAFA_TILES")) db->tiles_override = atoi(tv) == 2 ? 2u : atoi(tv) == 1 ? 1u : 0u;
+    if (const char *tv = getenv("SMAFA_TILES")) {
+        const int t = atoi(tv);
+        db->tiles_override = (t == 1 || t == 2 || t == 4 || t == 8) ? (uint32_t)t : 0u;
+    }
+    if (const char *lv = getenv("SMAFA_LAZY")) db->lazy = atoi(lv) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) db->n_cu = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&db->own_stream, hipStreamNonBlocking);
@@ -555,6 +599,14 @@ void smafa_db_destroy(smafa_db *db) {
 int smafa_set_query_block(smafa_db *db, uint32_t queries_per_block) {
     if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_set_query_block: NULL handle");
     db->qb_override = queries_per_block;
+    return SMAFA_OK;
+}
+
+int smafa_last_scan_plan(smafa_db *db, uint32_t *filter_plane_resident, uint32_t *tiles_per_wave, uint32_t *query_blocks) {
+    if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_last_scan_plan: NULL handle");
+    if (filter_plane_resident) *filter_plane_resident = db->plan_lazy;
+    if (tiles_per_wave) *tiles_per_wave = db->plan_tiles;
+    if (query_blocks) *query_blocks = db->plan_qblocks;
     return SMAFA_OK;
 }
 

@@ -49,6 +49,9 @@ __host__ __device__ constexpr int scan_min_waves(int ps, int w, int t) {
     const int regs = t * ps * w * 4 + 40;
     return regs <= 64 ? 8 : regs <= 80 ? 6 : regs <= 96 ? 5 : regs <= 128 ? 4 : regs <= 168 ? 3 : 2;
 }
+#ifndef SMAFA_CASCADE
+#define SMAFA_CASCADE 1  // 1: a one-word first-level bound in front of the folded bound (+7 % aa, +4 % nt measured)
+#endif
 #ifndef SMAFA_AND_PAIR
 #define SMAFA_AND_PAIR 1  // 1: the prefilter bounds two subjects with one popcount (weaker, cheaper: +5 % measured)
 #endif
@@ -136,8 +139,11 @@ __device__ __forceinline__ void emit(const ScanArgs &a, uint32_t q, uint32_t sub
 // one compare per wave step.  Only when some lane says yes does the wave compute the full distance
 // for that query (all planes, all words) and test it exactly.  Nothing is approximated: a pair is
 // skipped only when its lower bound already exceeds the query's bound.
+// A cheaper first level runs in front of it: popcount(S_f[0] XOR Q_f[0]) over the first 32 columns only (one
+// xor + one popcount per subject); the folded bound is evaluated only for queries that pass level 1.
 // If the prefilter stops paying (dense neighbourhoods: it passes for more than a quarter of a chunk's
-// queries) the wave switches to the plain full comparison and re-probes every 16th chunk.
+// queries) the wave switches to the plain full comparison and re-probes every 16th chunk; level 1 alone is
+// dropped the same way when it passes for more than half of a chunk's queries.
 // ---------------------------------------------------------------------------------------------
 // PS = planes stored per subject, PQ = planes per query record (PS < PQ only for the N-free nucleotide
 // store: subjects carry code bits 0-1, queries still carry the N bit, which mismatches every subject).
@@ -271,6 +277,7 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
     __syncthreads();
     int buf = 0;
     bool filter_on = a.use_filter != 0;
+    bool level1_on = true;
     uint32_t chunk_no = 0;
     for (uint32_t qc = q0; qc < q1; qc += kChunk, buf ^= 1, chunk_no++) {
         const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
@@ -281,46 +288,307 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
             const bool probe = a.use_filter && (filter_on || (chunk_no & 15u) == 0);
             if (probe) {
                 uint32_t passes = 0;  // wave-uniform: queries of this chunk that needed the full comparison
+                uint32_t level1_passes = 0;
+                // pinned to a scalar register: hipcc cannot see through __ballot that these flags are wave-uniform
+                // and would otherwise carry them as lane masks / VGPR counters through the hot loop
+                const bool l1 = __builtin_amdgcn_readfirstlane((int)level1_on) != 0;
                 for (uint32_t i = 0; i < nqc; i++, rec += RV) {
                     uint32_t qw[RS];
                     read_record(rec, qw, 0, HV);  // fast path: filter-plane words + bound slot only
                     const uint32_t nu = qw[BS];
                     uint32_t any = 0;
+                    bool go = true;  // wave-uniform: does this query reach the folded bound?
+#if SMAFA_CASCADE
+                    // level 1: word 0 of the filter plane only — popcount(s ^ q) over 32 columns, one xor + one
+                    // popcount per subject; weaker than the folded bound below but cheaper, and still exact
+                    if (W > 1 && l1) {
+                        uint32_t any1 = 0;
 #pragma unroll
-                    for (int t = 0; t < T; t++) {
-                        // lower bound on the filter plane, folded over the words
-                        uint32_t m0 = s[t][FP * W].x ^ qw[0], m1 = s[t][FP * W].y ^ qw[0];
-                        uint32_t m2 = s[t][FP * W].z ^ qw[0], m3 = s[t][FP * W].w ^ qw[0];
-#pragma unroll
-                        for (int w = 1; w < W; w++) {
-                            m0 = or_xor(m0, s[t][FP * W + w].x, qw[w]);
-                            m1 = or_xor(m1, s[t][FP * W + w].y, qw[w]);
-                            m2 = or_xor(m2, s[t][FP * W + w].z, qw[w]);
-                            m3 = or_xor(m3, s[t][FP * W + w].w, qw[w]);
+                        for (int t = 0; t < T; t++) {
+                            const uint32_t u0 = __builtin_popcount(s[t][FP * W].x ^ qw[0]) + nu;
+                            const uint32_t u1 = __builtin_popcount(s[t][FP * W].y ^ qw[0]) + nu;
+                            const uint32_t u2 = __builtin_popcount(s[t][FP * W].z ^ qw[0]) + nu;
+                            const uint32_t u3 = __builtin_popcount(s[t][FP * W].w ^ qw[0]) + nu;
+                            any1 = t ? or3(or3(u0, u1, u2), u3, any1) : (or3(u0, u1, u2) | u3);
                         }
-#if SMAFA_AND_PAIR
-                        // popcount(a & b) <= min(popcount a, popcount b): one popcount bounds two subjects
-                        const uint32_t t0 = __builtin_popcount(m0 & m1) + nu, t2 = __builtin_popcount(m2 & m3) + nu;
-                        any = t ? or3(any, t0, t2) : (t0 | t2);
-#else
-                        const uint32_t t0 = __builtin_popcount(m0) + nu, t1 = __builtin_popcount(m1) + nu;
-                        const uint32_t t2 = __builtin_popcount(m2) + nu, t3 = __builtin_popcount(m3) + nu;
-                        any = t ? or3(or3(t0, t1, t2), t3, any) : (or3(t0, t1, t2) | t3);
-#endif
+                        go = __ballot((int32_t)any1 < 0) != 0ull;  // nobody can qualify: next query
+                        level1_passes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(level1_passes + (go ? 1u : 0u)));
                     }
-                    // sign bit set <=> some lower bound <= bound
-                    if (__ballot((int32_t)any < 0) != 0ull) {  // wave-uniform branch, rare
-                        passes++;
-                        read_record(rec, qw, HV, RV);
-                        full_compare(qw, qc + i);
+#endif
+                    if (go) {
+#pragma unroll
+                        for (int t = 0; t < T; t++) {
+                            // lower bound on the filter plane, folded over the words
+                            uint32_t m0 = s[t][FP * W].x ^ qw[0], m1 = s[t][FP * W].y ^ qw[0];
+                            uint32_t m2 = s[t][FP * W].z ^ qw[0], m3 = s[t][FP * W].w ^ qw[0];
+#pragma unroll
+                            for (int w = 1; w < W; w++) {
+                                m0 = or_xor(m0, s[t][FP * W + w].x, qw[w]);
+                                m1 = or_xor(m1, s[t][FP * W + w].y, qw[w]);
+                                m2 = or_xor(m2, s[t][FP * W + w].z, qw[w]);
+                                m3 = or_xor(m3, s[t][FP * W + w].w, qw[w]);
+                            }
+#if SMAFA_AND_PAIR
+                            // popcount(a & b) <= min(popcount a, popcount b): one popcount bounds two subjects
+                            const uint32_t t0 = __builtin_popcount(m0 & m1) + nu, t2 = __builtin_popcount(m2 & m3) + nu;
+                            any = t ? or3(any, t0, t2) : (t0 | t2);
+#else
+                            const uint32_t t0 = __builtin_popcount(m0) + nu, t1 = __builtin_popcount(m1) + nu;
+                            const uint32_t t2 = __builtin_popcount(m2) + nu, t3 = __builtin_popcount(m3) + nu;
+                            any = t ? or3(or3(t0, t1, t2), t3, any) : (or3(t0, t1, t2) | t3);
+#endif
+                        }
+                        // sign bit set <=> some lower bound <= bound
+                        if (__ballot((int32_t)any < 0) != 0ull) {  // wave-uniform branch, rare
+                            passes++;
+                            read_record(rec, qw, HV, RV);
+                            full_compare(qw, qc + i);
+                        }
                     }
                 }
                 filter_on = passes * 4u <= nqc;
+                // level 1 earns its keep only while it rejects most queries; like the prefilter as a whole it is
+                // re-tried on every 16th chunk
+                level1_on = l1 ? level1_passes * 2u <= nqc : (chunk_no & 15u) == 15u;
             } else {
                 for (uint32_t i = 0; i < nqc; i++, rec += RV) {
                     uint32_t qw[RS];
                     read_record(rec, qw, 0, RV);
                     full_compare(qw, qc + i);
+                }
+            }
+        }
+        if (more) commit(buf ^ 1, qc + kChunk);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Filter-plane-resident form of the scan.
+//
+// With the first-level bound a query usually costs one xor + one popcount per subject, so what is left to
+// amortise is the per-query work (LDS read, OR tree, compare, branches) — over more subjects per lane — and
+// the registers that hold planes the fast path never touches.  Here a lane keeps ONLY the filter plane's
+// W words of its 4*T subjects (T wave tiles per wave) and
+//   * levels 1 and 2 of the prefilter run from those registers, exactly as in scan_kernel;
+//   * when a query survives them (rare), the other planes of the tiles that survived are fetched from
+//     L2/HBM for that one comparison;
+//   * when the prefilter stops paying for a wave (dense neighbourhoods), the wave walks the 64-query chunk
+//     once per tile with that tile's planes loaded into registers: the plain full comparison.
+// Sparse-hit scans then stream only W/(PS*W) of the store from HBM (1/5 for amino acids).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int lazy_min_waves(int ps, int w, int t) {
+    const int regs = t * w * 4 + ps * w * 4 + 44;  // filter words of T tiles + one tile's planes (transient) + working set
+    return regs <= 64 ? 8 : regs <= 80 ? 6 : regs <= 96 ? 5 : regs <= 128 ? 4 : regs <= 168 ? 3 : 2;
+}
+
+template <int PS, int PQ, int W, int T, bool SEED>
+__global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kernel(const uint4 *__restrict__ planes,
+                                                                                  const uint32_t *__restrict__ qrec,
+                                                                                  ScanArgs a) {
+    constexpr int RS = qrec_stride(PQ, W);
+    constexpr int RV = RS / 4;
+    constexpr int NV = (kChunk * RV + 255) / 256;
+    constexpr int FP = filter_plane(PQ);
+    static_assert(FP < PS && PS <= PQ, "the filter plane must be one the subjects store");
+    constexpr int BS = bound_slot(W);
+    constexpr int HV = (W + 1 + 3) / 4;
+    __shared__ uint4 stage[2][kChunk * RV];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t wg_tile = blockIdx.x % a.n_wg_tiles;
+    const uint32_t qblock = blockIdx.x / a.n_wg_tiles;
+    const uint32_t tile0 = a.tile_begin + (wg_tile * kWgWaves + wave) * T;
+    const bool active = tile0 < a.tile_end;
+
+    // filter-plane words of this lane's 4*T subjects; tile slots past the range hold a copy of tile_begin
+    // (valid memory) and are ignored wherever rows could come out of them
+    uint4 f[T][W];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        const bool live = tile0 + t < a.tile_end;
+        const uint4 *src = planes + (size_t)(live ? tile0 + t : a.tile_begin) * (PS * W * 64) + lane;
+#pragma unroll
+        for (int w = 0; w < W; w++) f[t][w] = src[(FP * W + w) * 64];
+    }
+    const uint32_t q0 = a.q_begin + qblock * a.qb_size;
+    const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
+
+    uint4 pre[NV];
+    auto fetch = [&](uint32_t qc) {
+        const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
+        const uint4 *src = reinterpret_cast<const uint4 *>(qrec + (size_t)qc * RS);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const uint32_t idx = tid + v * 256;
+            if (idx < nqc * RV) {
+                uint4 x = src[idx];
+                if (idx % RV == BS / 4) {
+                    const uint32_t nu = ~(a.thr ? ld_relaxed(a.thr + qc + idx / RV) : a.thr0);
+                    if ((BS & 3) == 0) x.x = nu;
+                    else if ((BS & 3) == 1) x.y = nu;
+                    else if ((BS & 3) == 2) x.z = nu;
+                    else x.w = nu;
+                }
+                pre[v] = x;
+            }
+        }
+    };
+    auto commit = [&](int buf, uint32_t qc) {
+        const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const uint32_t idx = tid + v * 256;
+            if (idx < nqc * RV) stage[buf][idx] = pre[v];
+        }
+    };
+    auto read_record = [&](const uint4 *rec, uint32_t(&qw)[RS], int from, int to) {
+#pragma unroll
+        for (int v = from; v < to; v++) {
+            const uint4 x = rec[v];
+            qw[4 * v + 0] = x.x;
+            qw[4 * v + 1] = x.y;
+            qw[4 * v + 2] = x.z;
+            qw[4 * v + 3] = x.w;
+        }
+    };
+    auto load_tile = [&](uint32_t tile, uint4(&s)[PS * W]) {  // all planes of one wave tile: L2/HBM -> registers
+        const uint4 *src = planes + (size_t)tile * (PS * W * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < PS * W; i++) s[i] = src[i * 64];
+    };
+    // full comparison of one query against the 4 subjects this lane owns in `tile`
+    auto full_compare = [&](const uint4(&s)[PS * W], uint32_t tile, const uint32_t(&qw)[RS], uint32_t q) {
+        const uint32_t U = ~qw[BS];
+        uint32_t d[4];
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            uint32_t extra = 0;
+#pragma unroll
+            for (int p = PS; p < PQ; p++) extra |= qw[qslot(PQ, W, p, w)];
+            uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
+#pragma unroll
+            for (int p = 0; p < PS; p++) {
+                const uint4 v = s[p * W + w];
+                const uint32_t qv = qw[qslot(PQ, W, p, w)];
+                const bool first = p == 0 && PS == PQ;
+                m0 = first ? (v.x ^ qv) : or_xor(m0, v.x, qv);
+                m1 = first ? (v.y ^ qv) : or_xor(m1, v.y, qv);
+                m2 = first ? (v.z ^ qv) : or_xor(m2, v.z, qv);
+                m3 = first ? (v.w ^ qv) : or_xor(m3, v.w, qv);
+            }
+            d[0] = (w ? d[0] : 0u) + __builtin_popcount(m0);
+            d[1] = (w ? d[1] : 0u) + __builtin_popcount(m1);
+            d[2] = (w ? d[2] : 0u) + __builtin_popcount(m2);
+            d[3] = (w ? d[3] : 0u) + __builtin_popcount(m3);
+        }
+        const uint32_t subj0 = tile * kWaveTile + lane * 4u;
+        if (SEED) {
+            uint32_t lo = 0xffffffffu;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (subj0 + k < a.n_subjects) lo = min(lo, d[k]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+            if (lane == 0 && lo < U) atomicMin(a.thr + q, lo);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, q, subj0 + k, d[k]);
+        }
+    };
+
+    if (q0 < q1) {
+        fetch(q0);
+        commit(0, q0);
+    }
+    __syncthreads();
+    int buf = 0;
+    bool filter_on = a.use_filter != 0;
+    bool level1_on = true;
+    uint32_t chunk_no = 0;
+    for (uint32_t qc = q0; qc < q1; qc += kChunk, buf ^= 1, chunk_no++) {
+        const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
+        const bool more = qc + kChunk < q1;
+        if (more) fetch(qc + kChunk);
+        if (active) {
+            const bool probe = a.use_filter && (filter_on || (chunk_no & 15u) == 0);
+            if (probe) {
+                const uint4 *rec = &stage[buf][0];
+                uint32_t passes = 0, level1_passes = 0;
+                // pinned to a scalar: hipcc cannot see through __ballot that these flags are wave-uniform
+                const bool l1 = __builtin_amdgcn_readfirstlane((int)level1_on) != 0;
+                for (uint32_t i = 0; i < nqc; i++, rec += RV) {
+                    uint32_t qw[RS];
+                    read_record(rec, qw, 0, HV);
+                    const uint32_t nu = qw[BS];
+                    bool go = true;
+                    if (W > 1 && l1) {  // level 1: word 0 of the filter plane
+                        uint32_t any1 = 0;
+#pragma unroll
+                        for (int t = 0; t < T; t++) {
+                            const uint32_t u0 = __builtin_popcount(f[t][0].x ^ qw[0]) + nu;
+                            const uint32_t u1 = __builtin_popcount(f[t][0].y ^ qw[0]) + nu;
+                            const uint32_t u2 = __builtin_popcount(f[t][0].z ^ qw[0]) + nu;
+                            const uint32_t u3 = __builtin_popcount(f[t][0].w ^ qw[0]) + nu;
+                            any1 = t ? or3(or3(u0, u1, u2), u3, any1) : (or3(u0, u1, u2) | u3);
+                        }
+                        go = __ballot((int32_t)any1 < 0) != 0ull;
+                        level1_passes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(level1_passes + (go ? 1u : 0u)));
+                    }
+                    if (go) {  // level 2: the filter plane folded over its words, two subjects per popcount
+                        uint32_t any = 0;
+                        uint32_t tsign[T];
+#pragma unroll
+                        for (int t = 0; t < T; t++) {
+                            uint32_t m0 = f[t][0].x ^ qw[0], m1 = f[t][0].y ^ qw[0];
+                            uint32_t m2 = f[t][0].z ^ qw[0], m3 = f[t][0].w ^ qw[0];
+#pragma unroll
+                            for (int w = 1; w < W; w++) {
+                                m0 = or_xor(m0, f[t][w].x, qw[w]);
+                                m1 = or_xor(m1, f[t][w].y, qw[w]);
+                                m2 = or_xor(m2, f[t][w].z, qw[w]);
+                                m3 = or_xor(m3, f[t][w].w, qw[w]);
+                            }
+                            tsign[t] = (__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu);
+                            any |= tsign[t];
+                        }
+                        if (__ballot((int32_t)any < 0) != 0ull) {  // level 3, rare: fetch planes, compare exactly
+                            passes++;
+                            read_record(rec, qw, HV, RV);
+                            uint32_t live = 0;  // wave-uniform mask of the tiles that survived level 2
+#pragma unroll
+                            for (int t = 0; t < T; t++)
+                                if (__ballot((int32_t)tsign[t] < 0) != 0ull) live |= 1u << t;
+                            live = (uint32_t)__builtin_amdgcn_readfirstlane((int)live);
+                            while (live) {  // ONE copy of the comparison code, whatever T is
+                                const uint32_t t = (uint32_t)__builtin_ctz(live);
+                                live &= live - 1;
+                                if (tile0 + t < a.tile_end) {
+                                    uint4 s[PS * W];
+                                    load_tile(tile0 + t, s);
+                                    full_compare(s, tile0 + t, qw, qc + i);
+                                }
+                            }
+                        }
+                    }
+                }
+                filter_on = passes * 4u <= nqc;
+                level1_on = l1 ? level1_passes * 2u <= nqc : (chunk_no & 15u) == 15u;
+            } else {
+                // dense neighbourhoods: one pass over the chunk per tile, that tile's planes in registers
+                for (int t = 0; t < T; t++) {
+                    if (tile0 + t >= a.tile_end) break;
+                    uint4 s[PS * W];
+                    load_tile(tile0 + t, s);
+                    const uint4 *rec = &stage[buf][0];
+                    for (uint32_t i = 0; i < nqc; i++, rec += RV) {
+                        uint32_t qw[RS];
+                        read_record(rec, qw, 0, RV);
+                        full_compare(s, tile0 + t, qw, qc + i);
+                    }
                 }
             }
         }
