@@ -16,8 +16,9 @@
 //     u32 planes[n_wave_tiles][P][W][256]      W = ceil(seq_len / 32)
 // element [t][p][w][i] = word w of plane p of subject t*256 + i.  A lane owns subjects
 // 4*lane .. 4*lane+3 of its wave's tile, so every load is one 16-byte global_load_dwordx4 per
-// lane, 1 KiB contiguous per wave instruction, and the whole tile (P*W KiB) is read exactly once
-// per query block and then lives in VGPRs while the wave walks the query block.
+// lane, 1 KiB contiguous per wave instruction; what a wave needs of its tiles is read once per query
+// block and then lives in VGPRs while the wave walks the block (all planes: scan_kernel; only the
+// prefilter's plane, the rest on demand: scan_lazy_kernel).
 //
 // Query records (u32 words, stride qrec_stride(P, W)):
 //     [ filter-plane words 0..W-1 | bound slot | the other planes' words ]
