@@ -205,15 +205,20 @@ static void launch_scan_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
 // measured 2 beats 1 for every store with W <= 2 even where it costs occupancy (profiles/r01_variant_tiles*.txt).
 // SMAFA_TILES=1|2|4 overrides (4: 2-plane store only).
 // The filter-plane-resident kernel wins where the prefilter prunes (sparse hits: +18 % aa, 5x less HBM traffic)
-// and loses 10-100 % where it cannot — a bound above ~half of the 32 columns level 1 looks at, e.g. best-hit
-// scans without --max-divergence (profiles/r01_lazy_vs_resident.txt).  Chosen per launch from the initial bound.
-constexpr uint32_t kLazyMaxBound = 16;
+// and loses 10-100 % where it cannot (profiles/r01_lazy_vs_resident.txt, r01_length_probe.txt).  Level 1 looks
+// at min(32, L) columns of one plane, where unrelated sequences differ in about half of them: it prunes while the
+// bound stays below about a quarter of those columns.  Chosen per launch from the initial bound, so best-hit scans
+// without --max-divergence (bound = L) and short sequences with a loose bound keep the all-planes kernel.
 static bool use_lazy(const smafa_db *db, uint32_t thr0) {
-    return db->lazy && db->use_filter && db->W == 2 && thr0 <= kLazyMaxBound;
+    const uint32_t cols = std::min<uint32_t>(32u, db->L);
+    return db->lazy && db->use_filter && db->W <= 4 && thr0 * 4u < cols;
 }
 
 static uint32_t tiles_per_wave(const smafa_db *db, bool lazy) {
-    if (lazy) return db->tiles_override == 8 ? 8u : 4u;
+    if (lazy) {
+        if (db->W >= 3) return 2u;  // the prefilter plane is 3-4 words per subject: 8 subjects per lane
+        return (db->W == 2 && db->tiles_override == 8) ? 8u : 4u;
+    }
     if (db->W > 2) return 1;
     if (db->tiles_override == 4) return db->P == 2 ? 4u : 2u;
     if (db->tiles_override == 1 || db->tiles_override == 2) return db->tiles_override;
@@ -222,13 +227,17 @@ static uint32_t tiles_per_wave(const smafa_db *db, bool lazy) {
 
 static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid, uint32_t T,
                         bool lazy) {
-    if (lazy) {  // filter-plane-resident kernel (L in 33..64)
-#define SMAFA_LAZY(PS_, PQ_, T_)                               \
-    if (db->P == PS_ && db->PQ == PQ_ && T == T_) {            \
-        launch_lazy_t<PS_, PQ_, 2, T_>(db, d_qrec, a, grid);   \
-        return;                                                \
+    if (lazy) {  // filter-plane-resident kernel
+#define SMAFA_LAZY(PS_, PQ_, W_, T_)                                  \
+    if (db->P == PS_ && db->PQ == PQ_ && db->W == W_ && T == T_) {    \
+        launch_lazy_t<PS_, PQ_, W_, T_>(db, d_qrec, a, grid);         \
+        return;                                                       \
     }
-        SMAFA_LAZY(2, 3, 4) SMAFA_LAZY(2, 3, 8) SMAFA_LAZY(3, 3, 4) SMAFA_LAZY(3, 3, 8) SMAFA_LAZY(5, 5, 4) SMAFA_LAZY(5, 5, 8)
+        SMAFA_LAZY(2, 3, 2, 4) SMAFA_LAZY(3, 3, 2, 4) SMAFA_LAZY(5, 5, 2, 4)
+        SMAFA_LAZY(2, 3, 2, 8) SMAFA_LAZY(3, 3, 2, 8) SMAFA_LAZY(5, 5, 2, 8)
+        SMAFA_LAZY(2, 3, 1, 4) SMAFA_LAZY(3, 3, 1, 4) SMAFA_LAZY(5, 5, 1, 4)
+        SMAFA_LAZY(2, 3, 3, 2) SMAFA_LAZY(3, 3, 3, 2) SMAFA_LAZY(5, 5, 3, 2)
+        SMAFA_LAZY(2, 3, 4, 2) SMAFA_LAZY(3, 3, 4, 2) SMAFA_LAZY(5, 5, 4, 2)
 #undef SMAFA_LAZY
     }
 #define SMAFA_CASE(PS_, PQ_, W_, T_)                          \

@@ -161,6 +161,9 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
     static_assert(FP < PS && PS <= PQ, "the filter plane must be one the subjects store");
     constexpr int BS = bound_slot(W);
     constexpr int HV = (W + 1 + 3) / 4;  // uint4s holding the filter words + bound slot
+    // two subjects per popcount only where the folded mask is dense enough to survive an AND (W >= 2);
+    // with a single word the bound is taken per subject
+    constexpr bool kPair = SMAFA_AND_PAIR && W > 1;
     __shared__ uint4 stage[2][kChunk * RV];
 
     const uint32_t tid = threadIdx.x;
@@ -329,15 +332,15 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
                                 m2 = or_xor(m2, s[t][FP * W + w].z, qw[w]);
                                 m3 = or_xor(m3, s[t][FP * W + w].w, qw[w]);
                             }
-#if SMAFA_AND_PAIR
-                            // popcount(a & b) <= min(popcount a, popcount b): one popcount bounds two subjects
-                            const uint32_t t0 = __builtin_popcount(m0 & m1) + nu, t2 = __builtin_popcount(m2 & m3) + nu;
-                            any = t ? or3(any, t0, t2) : (t0 | t2);
-#else
-                            const uint32_t t0 = __builtin_popcount(m0) + nu, t1 = __builtin_popcount(m1) + nu;
-                            const uint32_t t2 = __builtin_popcount(m2) + nu, t3 = __builtin_popcount(m3) + nu;
-                            any = t ? or3(or3(t0, t1, t2), t3, any) : (or3(t0, t1, t2) | t3);
-#endif
+                            if (kPair) {
+                                // popcount(a & b) <= min(popcount a, popcount b): one popcount bounds two subjects
+                                const uint32_t t0 = __builtin_popcount(m0 & m1) + nu, t2 = __builtin_popcount(m2 & m3) + nu;
+                                any = t ? or3(any, t0, t2) : (t0 | t2);
+                            } else {
+                                const uint32_t t0 = __builtin_popcount(m0) + nu, t1 = __builtin_popcount(m1) + nu;
+                                const uint32_t t2 = __builtin_popcount(m2) + nu, t3 = __builtin_popcount(m3) + nu;
+                                any = t ? or3(or3(t0, t1, t2), t3, any) : (or3(t0, t1, t2) | t3);
+                            }
                         }
                         // sign bit set <=> some lower bound <= bound
                         if (__ballot((int32_t)any < 0) != 0ull) {  // wave-uniform branch, rare
@@ -394,6 +397,7 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
     static_assert(FP < PS && PS <= PQ, "the filter plane must be one the subjects store");
     constexpr int BS = bound_slot(W);
     constexpr int HV = (W + 1 + 3) / 4;
+    constexpr bool kPair = SMAFA_AND_PAIR && W > 1;  // see scan_kernel
     __shared__ uint4 stage[2][kChunk * RV];
 
     const uint32_t tid = threadIdx.x;
@@ -553,7 +557,10 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
                                 m2 = or_xor(m2, f[t][w].z, qw[w]);
                                 m3 = or_xor(m3, f[t][w].w, qw[w]);
                             }
-                            tsign[t] = (__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu);
+                            tsign[t] = kPair ? ((__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu))
+                                             : (or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
+                                                    __builtin_popcount(m2) + nu) |
+                                                (__builtin_popcount(m3) + nu));
                             any |= tsign[t];
                         }
                         if (__ballot((int32_t)any < 0) != 0ull) {  // level 3, rare: fetch planes, compare exactly
