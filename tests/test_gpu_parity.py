@@ -471,3 +471,69 @@ def test_cli_edge_cases_match_oracle(tmp_path):
     (d / "c2.fna").write_bytes(b">1\nACGTACGTAC\n>2\nACGTACGTAA\n>3\nACGT\n>4\nACGTACGTAC\n")
     got, want = both_cli("cluster", "-i", str(d / "c2.fna"), "-d", "1")
     assert got.returncode == want.returncode == 101 and got.stdout == want.stdout and got.stdout.count("\n") == 2
+
+
+# ------------------------------------------------------------------ randomized differential sweep
+def test_randomized_cli_sweep_vs_oracle(tmp_path):
+    """40 random (length, store size, mutation load, flag set) draws through `smafa makedb|query|cluster`
+    against the oracle CLI: same stdout, same exit status"""
+    rng = np.random.default_rng(2024)
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for trial in range(40):
+        L = int(rng.choice([3, 9, 12, 13, 31, 32, 33, 47, 60, 64, 65, 100, 128, 131]))
+        n = int(rng.choice([1, 2, 5, 63, 64, 65, 300, 1500]))
+        nq = int(rng.integers(1, 40))
+        s = letters[rng.integers(0, 4, size=(n, L))]
+        if rng.random() < 0.5:
+            s[rng.random(size=s.shape) < 0.03] = ord("N")
+        if n > 4 and rng.random() < 0.7:  # duplicates and near-duplicates
+            s[n // 2] = s[0]
+            s[n - 1] = s[0]
+            s[n - 2, : L // 2] = s[0, : L // 2]
+        q = s[rng.integers(0, n, size=nq)].copy()
+        for r in q:
+            for _ in range(int(rng.integers(0, max(2, L // 4)))):
+                r[rng.integers(0, L)] = letters[rng.integers(0, 5)]
+        flags = []
+        if rng.random() < 0.6:
+            flags += ["--max-divergence", str(int(rng.integers(0, L + 2)))]
+        k = None
+        if rng.random() < 0.6:
+            k = int(rng.choice([1, 2, 3, 7, 50, 5000]))
+            flags += ["--max-num-hits", str(k)]
+        if k is not None and k > 1 and rng.random() < 0.4:
+            flags += ["--limit-per-sequence", str(int(rng.integers(1, 4)))]
+        d = tmp_path / f"t{trial}"
+        d.mkdir()
+        sf, qf, db = str(d / "s.fna"), str(d / "q.fna"), str(d / "db")
+        oracle.write_fasta(sf, [bytes(r) for r in s])
+        oracle.write_fasta(qf, [bytes(r) for r in q])
+        assert cli("makedb", "-i", sf, "-d", db).returncode == 0
+        got, want = both_cli("query", "-d", db, "-q", qf, *flags)
+        assert got.returncode == want.returncode, (trial, L, n, flags, got.stderr, want.stderr)
+        assert got.stdout == want.stdout, (trial, L, n, nq, flags)
+        D = str(int(rng.integers(0, max(2, L // 3))))
+        got, want = both_cli("cluster", "-i", sf, "-d", D)
+        assert got.returncode == want.returncode == 0 and got.stdout == want.stdout, (trial, L, n, D)
+
+
+def test_randomized_api_sweep_vs_oracle_aa():
+    """amino-acid stores through the C ABI: random lengths / sizes / bounds / k against the code-byte oracle"""
+    rng = np.random.default_rng(777)
+    for trial in range(30):
+        L = int(rng.choice([5, 20, 31, 33, 60, 64, 70, 96, 127, 128, 160]))
+        n = int(rng.choice([1, 100, 255, 257, 1024, 4097, 9000]))
+        nq = int(rng.integers(1, 60))
+        n_letters = int(rng.choice([2, 4, 20, 28]))
+        s, q = planted(rng, n, L, n_letters, nq, min(L, 9))
+        store = smafa_amd.SubjectStore(L, smafa_amd.ALPHABET_AA)
+        half = n // 2
+        store.push(s[:half])
+        store.push(s[half:])
+        D = None if rng.random() < 0.3 else int(rng.integers(0, L + 1))
+        k = None if rng.random() < 0.5 else int(rng.choice([1, 2, 4, 9, 100]))
+        got = store.scan(q, max_divergence=D, max_num_hits=k)
+        full = oracle.scan_codes(s, q, L if D is None else D)
+        want = full if k is None else expected_with_k(full, k)
+        assert got.tobytes() == want.tobytes(), (trial, L, n, nq, n_letters, D, k)
+        store.close()
