@@ -274,9 +274,9 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
                         uint32_t tile_end, uint32_t k_tight, uint32_t thr0, smafa_hit *d_hits, uint64_t cap,
                         unsigned long long *d_count) {
     ScanArgs a;
-    const bool specialised = db->W <= 4;  // else scan_generic_kernel: one wave tile per wave
+    const bool specialised = db->W <= 4;  // else scan_generic_kernel
     const bool lazy = specialised && use_lazy(db, thr0);
-    const uint32_t T = specialised ? tiles_per_wave(db, lazy) : 1u;
+    const uint32_t T = specialised ? tiles_per_wave(db, lazy) : (uint32_t)kGenericTiles;
     a.tile_begin = tile_begin;
     a.tile_end = tile_end;
     a.n_wg_tiles = (tile_end - tile_begin + kWgWaves * T - 1) / (kWgWaves * T);

@@ -605,8 +605,12 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
     }
 }
 
-// Any (planes, words) shape: subject words are re-read from the tile (L1/L2) per query instead of
-// being held in registers.  Correct for every seq_len; used when no specialisation exists.
+// Any (planes, words) shape — the fallback for lengths without a specialisation (L > 128).  A lane keeps word 0
+// of the prefilter plane of its 16 subjects (4 wave tiles) in registers and applies the level-1 bound of the
+// specialised kernels (exact: popcount over the first 32 columns of one plane <= distance); only for queries
+// that survive it are the subjects' words re-read from L2/HBM, plane by plane, for the full comparison.
+constexpr int kGenericTiles = 4;
+
 __global__ __launch_bounds__(256) void scan_generic_kernel(const uint4 *__restrict__ planes,
                                                            const uint32_t *__restrict__ qrec, ScanArgs a, uint32_t PS,
                                                            uint32_t PQ, uint32_t W, uint32_t QS) {
@@ -614,37 +618,60 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(const uint4 *__restri
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t wg_tile = blockIdx.x % a.n_wg_tiles;
     const uint32_t qblock = blockIdx.x / a.n_wg_tiles;
-    const uint32_t tile = a.tile_begin + wg_tile * kWgWaves + wave;
-    if (tile >= a.tile_end) return;  // no barrier in this kernel
-    const uint4 *t = planes + (size_t)tile * ((size_t)PS * W * 64) + lane;
-    const uint32_t subj0 = tile * kWaveTile + lane * 4u;
+    const uint32_t tile0 = a.tile_begin + (wg_tile * kWgWaves + wave) * kGenericTiles;
+    if (tile0 >= a.tile_end) return;  // no barrier in this kernel
+    const uint32_t FP = (uint32_t)filter_plane((int)PQ);
+    const size_t tile_stride = (size_t)PS * W * 64;
+    uint4 f[kGenericTiles];
+#pragma unroll
+    for (int t = 0; t < kGenericTiles; t++)
+        f[t] = tile0 + t < a.tile_end ? planes[(size_t)(tile0 + t) * tile_stride + (size_t)FP * W * 64 + lane]
+                                      : make_uint4(0, 0, 0, 0);
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
     const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
     for (uint32_t q = q0; q < q1; q++) {
         const uint32_t U = a.thr ? ld_relaxed(a.thr + q) : a.thr0;
         const uint32_t *qr = qrec + (size_t)q * QS;
-        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-        for (uint32_t w = 0; w < W; w++) {
-            uint32_t extra = 0;
-            for (uint32_t p = PS; p < PQ; p++) extra |= qr[qslot((int)PQ, (int)W, (int)p, (int)w)];
-            uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
-            for (uint32_t p = 0; p < PS; p++) {
-                const uint4 v = t[(p * W + w) * 64];
-                const uint32_t qv = qr[qslot((int)PQ, (int)W, (int)p, (int)w)];
-                m0 = or_xor(m0, v.x, qv);
-                m1 = or_xor(m1, v.y, qv);
-                m2 = or_xor(m2, v.z, qv);
-                m3 = or_xor(m3, v.w, qv);
-            }
-            d0 += __builtin_popcount(m0);
-            d1 += __builtin_popcount(m1);
-            d2 += __builtin_popcount(m2);
-            d3 += __builtin_popcount(m3);
+        bool go = true;
+        if (a.use_filter) {
+            const uint32_t q0w = qr[0], nu = ~U;  // slot 0 = word 0 of the prefilter plane
+            uint32_t any = 0;
+#pragma unroll
+            for (int t = 0; t < kGenericTiles; t++)
+                any |= or3(__builtin_popcount(f[t].x ^ q0w) + nu, __builtin_popcount(f[t].y ^ q0w) + nu,
+                           __builtin_popcount(f[t].z ^ q0w) + nu) |
+                       (__builtin_popcount(f[t].w ^ q0w) + nu);
+            go = __ballot((int32_t)any < 0) != 0ull;  // wave-uniform
         }
-        if (d0 <= U && subj0 + 0 < a.n_subjects) emit(a, q, subj0 + 0, d0);
-        if (d1 <= U && subj0 + 1 < a.n_subjects) emit(a, q, subj0 + 1, d1);
-        if (d2 <= U && subj0 + 2 < a.n_subjects) emit(a, q, subj0 + 2, d2);
-        if (d3 <= U && subj0 + 3 < a.n_subjects) emit(a, q, subj0 + 3, d3);
+        if (!go) continue;
+        for (uint32_t t = 0; t < (uint32_t)kGenericTiles; t++) {
+            const uint32_t tile = tile0 + t;
+            if (tile >= a.tile_end) break;
+            const uint4 *src = planes + (size_t)tile * tile_stride + lane;
+            const uint32_t subj0 = tile * kWaveTile + lane * 4u;
+            uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+            for (uint32_t w = 0; w < W; w++) {
+                uint32_t extra = 0;
+                for (uint32_t p = PS; p < PQ; p++) extra |= qr[qslot((int)PQ, (int)W, (int)p, (int)w)];
+                uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
+                for (uint32_t p = 0; p < PS; p++) {
+                    const uint4 v = src[(p * W + w) * 64];
+                    const uint32_t qv = qr[qslot((int)PQ, (int)W, (int)p, (int)w)];
+                    m0 = or_xor(m0, v.x, qv);
+                    m1 = or_xor(m1, v.y, qv);
+                    m2 = or_xor(m2, v.z, qv);
+                    m3 = or_xor(m3, v.w, qv);
+                }
+                d0 += __builtin_popcount(m0);
+                d1 += __builtin_popcount(m1);
+                d2 += __builtin_popcount(m2);
+                d3 += __builtin_popcount(m3);
+            }
+            if (d0 <= U && subj0 + 0 < a.n_subjects) emit(a, q, subj0 + 0, d0);
+            if (d1 <= U && subj0 + 1 < a.n_subjects) emit(a, q, subj0 + 1, d1);
+            if (d2 <= U && subj0 + 2 < a.n_subjects) emit(a, q, subj0 + 2, d2);
+            if (d3 <= U && subj0 + 3 < a.n_subjects) emit(a, q, subj0 + 3, d3);
+        }
     }
 }
 
