@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../engine.h"
@@ -75,30 +76,51 @@ extern "C" {
 int smafa_dbfile_write(const char *path, int alphabet, const uint8_t *codes, uint64_t n, uint32_t seq_len) {
     if (!path || (!codes && n)) return set_error(SMAFA_ERR_INVALID, "smafa_dbfile_write: NULL argument");
     std::vector<uint8_t> b;
+    std::vector<std::vector<uint8_t>> parts;  // window bytes, one buffer per worker, in row order
+    std::vector<uint8_t> tail;
     if (alphabet == SMAFA_ALPHABET_NT) {
         const size_t nw = ((size_t)seq_len + 11) / 12;
-        b.reserve(16 + (size_t)n * (1 + nw * 9));
         put_varint(b, SMAFA_DB_VERSION);
         put_varint(b, n);
-        for (uint64_t j = 0; j < n; j++) {
-            const uint8_t *row = codes + (size_t)j * seq_len;
-            put_varint(b, nw);
-            for (size_t w = 0; w < nw; w++) {
-                uint64_t word = 0;
-                const size_t lim = std::min<size_t>(12, seq_len - w * 12);
-                for (size_t i = 0; i < lim; i++) {
-                    const uint8_t c = row[w * 12 + i];
-                    if (c > 4) return set_error(SMAFA_ERR_INVALID, "code %u is not a nucleotide code", c);
-                    word |= (uint64_t)kOneHotOfCode[c] << (5 * i);
+        unsigned n_threads = n >= (1u << 20) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        parts.resize(n_threads);
+        std::vector<int> bad(n_threads, -1);
+        auto encode_rows = [&](unsigned t) {
+            const uint64_t lo = n * t / n_threads, hi = n * (t + 1) / n_threads;
+            std::vector<uint8_t> &out = parts[t];
+            out.reserve((size_t)(hi - lo) * (1 + nw * 9));
+            for (uint64_t j = lo; j < hi; j++) {
+                const uint8_t *row = codes + (size_t)j * seq_len;
+                put_varint(out, nw);
+                for (size_t w = 0; w < nw; w++) {
+                    uint64_t word = 0;
+                    const size_t lim = std::min<size_t>(12, seq_len - w * 12);
+                    for (size_t i = 0; i < lim; i++) {
+                        const uint8_t c = row[w * 12 + i];
+                        if (c > 4) {
+                            bad[t] = c;
+                            return;
+                        }
+                        word |= (uint64_t)kOneHotOfCode[c] << (5 * i);
+                    }
+                    put_varint(out, word);
                 }
-                put_varint(b, word);
             }
-        }
-        if (n == 0) {
-            b.push_back(0);  // len: None
+        };
+        if (n_threads > 1) {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < n_threads; t++) pool.emplace_back(encode_rows, t);
+            for (auto &th : pool) th.join();
         } else {
-            b.push_back(1);
-            put_varint(b, seq_len);
+            encode_rows(0);
+        }
+        for (int c : bad)
+            if (c >= 0) return set_error(SMAFA_ERR_INVALID, "code %d is not a nucleotide code", c);
+        if (n == 0) {
+            tail.push_back(0);  // len: None
+        } else {
+            tail.push_back(1);
+            put_varint(tail, seq_len);
         }
     } else if (alphabet == SMAFA_ALPHABET_AA) {
         put_varint(b, 3);
@@ -111,7 +133,9 @@ int smafa_dbfile_write(const char *path, int alphabet, const uint8_t *codes, uin
     }
     FILE *f = fopen(path, "wb");
     if (!f) return set_error(SMAFA_ERR_IO, "%s: %s", path, strerror(errno));
-    const bool ok = fwrite(b.data(), 1, b.size(), f) == b.size();
+    bool ok = fwrite(b.data(), 1, b.size(), f) == b.size();
+    for (const std::vector<uint8_t> &part : parts) ok = ok && fwrite(part.data(), 1, part.size(), f) == part.size();
+    ok = ok && fwrite(tail.data(), 1, tail.size(), f) == tail.size();
     if (fclose(f) != 0 || !ok) return set_error(SMAFA_ERR_IO, "%s: write error", path);
     return SMAFA_OK;
 }
@@ -160,9 +184,127 @@ int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t
     uint64_t cnt = 0;
     if (!get_varint(p, len, pos, 10, cnt)) return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
     // The sequence length comes LAST in the file (Option<NonZeroUsize> after the windows), but the first
-    // window's word count nw bounds it: (nw-1)*12 < L <= nw*12.  Windows are decoded straight into rows of
-    // nw*12 codes through a 32-entry table (one-hot 5 bits -> code; 254 = empty slot, 255 = invalid,
-    // src/lib.rs:120-129), then checked against L and compacted if L is not a multiple of 12.
+    // window's word count nw bounds it: (nw-1)*12 < L <= nw*12.
+    uint64_t nw = 0;
+    if (cnt) {
+        size_t peek = pos;
+        if (!get_varint(p, len, peek, 10, nw)) return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
+        if (nw == 0 || nw > (1u << 26) || cnt > len / nw + 1) return set_error(SMAFA_ERR_FORMAT, "%s: corrupt store", path);
+    }
+    const size_t stride = (size_t)nw * 12;
+
+    // Pass 1 — where do the windows end, and where can worker threads start?  Every window is
+    // varint(nw) + nw varints.  A worker finds a window boundary inside its byte range by local
+    // resynchronisation (a byte equal to nw followed by 48 windows that parse), and the pass is accepted only if
+    // every worker's walk lands exactly on the next worker's start and the window counts add up to cnt;
+    // otherwise (or for small files, or nw = 1 where the trailer byte is ambiguous) one thread walks the file.
+    struct Span {
+        size_t begin = 0, end = 0;
+        uint64_t first = 0, count = 0;
+        bool ok = true;
+    };
+    const size_t windows_begin = pos;
+    unsigned n_threads = 1;
+    if (cnt >= (1u << 20) && nw >= 2 && nw < 0x80) n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<Span> spans(n_threads);
+    auto walk = [&](size_t from, size_t stop, uint64_t max_windows, size_t &at, uint64_t &count) -> bool {
+        // skip whole windows from `from` until position >= stop or max_windows reached
+        at = from;
+        count = 0;
+        while (at < stop && count < max_windows) {
+            uint64_t k = 0;
+            size_t q = at;
+            if (!get_varint(p, len, q, 10, k) || k != nw) return false;
+            for (uint64_t w = 0; w < nw; w++) {
+                int i = 0;
+                for (; i < 10 && q < len && (p[q] & 0x80); i++) q++;
+                if (i == 10 || q >= len) return false;
+                q++;
+            }
+            at = q;
+            count++;
+        }
+        return true;
+    };
+    bool parallel_ok = n_threads > 1;
+    if (parallel_ok) {
+        const size_t chunk = (len - windows_begin) / n_threads;
+        std::vector<size_t> starts(n_threads + 1, len);
+        starts[0] = windows_begin;
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < n_threads; t++)
+            pool.emplace_back([&, t] {
+                const size_t lo = windows_begin + chunk * t;
+                for (size_t o = lo; o < lo + 4096 && o + 1 < len; o++) {
+                    if (p[o] != (uint8_t)nw) continue;
+                    size_t at;
+                    uint64_t c;
+                    if (walk(o, len, 48, at, c) && c == 48) {
+                        starts[t] = o;
+                        return;
+                    }
+                }
+                starts[t] = 0;  // no boundary found
+            });
+        for (auto &th : pool) th.join();
+        for (unsigned t = 1; t < n_threads; t++)
+            if (starts[t] == 0 || starts[t] <= starts[t - 1]) parallel_ok = false;
+        if (parallel_ok) {
+            pool.clear();
+            for (unsigned t = 0; t < n_threads; t++)
+                pool.emplace_back([&, t] {
+                    Span &sp = spans[t];
+                    sp.begin = starts[t];
+                    // the last range is walked afterwards, once the others say how many windows remain for it
+                    if (t + 1 < n_threads) sp.ok = walk(sp.begin, starts[t + 1], UINT64_MAX, sp.end, sp.count);
+                });
+            for (auto &th : pool) th.join();
+            uint64_t total = 0;
+            for (unsigned t = 0; t + 1 < n_threads; t++) {
+                if (!spans[t].ok || spans[t].end != starts[t + 1]) parallel_ok = false;
+                total += spans[t].count;
+            }
+            if (parallel_ok) {
+                Span &last = spans[n_threads - 1];
+                size_t at = 0;
+                uint64_t c = 0;
+                if (cnt < total || !walk(last.begin, len, cnt - total, at, c) || c != cnt - total) parallel_ok = false;
+                last.end = at;
+                last.count = c;
+                last.ok = true;
+            }
+            if (parallel_ok) {
+                uint64_t first = 0;
+                for (Span &sp : spans) {
+                    sp.first = first;
+                    first += sp.count;
+                }
+            }
+        }
+    }
+    if (!parallel_ok) {
+        spans.assign(1, Span());
+        spans[0].begin = windows_begin;
+        if (!walk(windows_begin, len, cnt, spans[0].end, spans[0].count) || spans[0].count != cnt)
+            return set_error(SMAFA_ERR_FORMAT, cnt ? "%s: malformed window list" : "DeserializeUnexpectedEnd", path);
+        n_threads = 1;
+    }
+    pos = spans.back().end;
+    if (cnt == 0) pos = windows_begin;
+    if (pos >= len) return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
+    const uint8_t tag = p[pos++];
+    uint64_t L = 0;
+    if (tag == 1) {
+        if (!get_varint(p, len, pos, 10, L) || L == 0) return set_error(SMAFA_ERR_FORMAT, "DeserializeBadEncoding");
+    } else if (tag != 0) {
+        return set_error(SMAFA_ERR_FORMAT, "DeserializeBadOption");
+    }
+    if (cnt && (L == 0 || (L + 11) / 12 != nw || L > 0xffffffffull))
+        return set_error(SMAFA_ERR_FORMAT, "%s: sequence length does not match the window size", path);
+
+    // Pass 2 — decode: each window's words go straight into a row of nw*12 codes through a 32-entry table
+    // (one-hot 5 bits -> code; 254 = empty slot, 255 = invalid, src/lib.rs:120-129); columns < L must hold a
+    // symbol (the reference's get_as_string panics otherwise), slots past L are ignored.
     static const struct OneHot {
         uint8_t t[32];
         OneHot() {
@@ -171,90 +313,52 @@ int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t
             t[16] = 0, t[8] = 1, t[4] = 2, t[2] = 3, t[1] = 4;
         }
     } onehot;
-    uint64_t nw = 0;
-    uint8_t *wide = nullptr;
-    size_t stride = 0;
-    for (uint64_t j = 0; j < cnt; j++) {
-        uint64_t k = 0;
-        if (!get_varint(p, len, pos, 10, k)) {
-            free(wide);
-            return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
-        }
-        if (j == 0) {
-            nw = k;
-            if (nw == 0 || nw > (1u << 26) || cnt > len / nw + 1) return set_error(SMAFA_ERR_FORMAT, "%s: corrupt store", path);
-            stride = (size_t)nw * 12;
-            wide = (uint8_t *)malloc(std::max<size_t>((size_t)cnt * stride, 1));
-            if (!wide) return set_error(SMAFA_ERR_IO, "out of memory");
-        } else if (k != nw) {
-            free(wide);
-            return set_error(SMAFA_ERR_FORMAT, "%s: windows of unequal size", path);
-        }
-        uint8_t *row = wide + (size_t)j * stride;
-        for (uint64_t w = 0; w < nw; w++) {
-            uint64_t v = 0;
-            if (pos + 10 <= len) {  // fast path: a whole varint is in range, no per-byte bounds checks
-                const uint8_t *q = p + pos;
+    uint8_t *wide = (uint8_t *)malloc(std::max<size_t>((size_t)cnt * stride, 1));
+    if (!wide) return set_error(SMAFA_ERR_IO, "out of memory");
+    std::vector<int> bad_symbol(spans.size(), -1);  // per span: offending 5-bit value, or -1
+    auto decode = [&](size_t si) {
+        const Span &sp = spans[si];
+        size_t q = sp.begin;
+        for (uint64_t j = sp.first; j < sp.first + sp.count; j++) {
+            q++;  // varint(nw): one byte, nw < 128 (or the sequential path's walk verified it)
+            if (nw >= 0x80) {  // multi-byte count (only reachable on the one-thread path)
+                q--;
+                uint64_t k;
+                get_varint(p, len, q, 10, k);
+            }
+            uint8_t *row = wide + (size_t)j * stride;
+            for (uint64_t w = 0; w < nw; w++) {
+                uint64_t v = 0;
                 int i = 0;
-                for (; i < 10; i++) {
-                    v |= (uint64_t)(q[i] & 0x7f) << (7 * i);
-                    if (!(q[i] & 0x80)) break;
+                for (;; i++) {  // pass 1 proved every varint terminates within 10 bytes inside the buffer
+                    v |= (uint64_t)(p[q + i] & 0x7f) << (7 * i);
+                    if (!(p[q + i] & 0x80)) break;
                 }
-                if (i == 10 || (i == 9 && q[9] > 1)) {
-                    free(wide);
-                    return set_error(SMAFA_ERR_FORMAT, "DeserializeBadVarint");
-                }
-                pos += (size_t)i + 1;
-            } else if (!get_varint(p, len, pos, 10, v)) {
-                free(wide);
-                return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
+                q += (size_t)i + 1;
+                uint8_t *dst = row + w * 12;
+                for (int c = 0; c < 12; c++) dst[c] = onehot.t[(v >> (5 * c)) & 31u];
+                if (v >> 60) bad_symbol[si] = (int)(v >> 60);  // top 4 bits are never set by from_bytes
             }
-            if (v >> 60) {  // 12 symbols x 5 bits: the top 4 bits are never set by from_bytes
-                free(wide);
-                return set_error(SMAFA_ERR_PANIC, "Invalid character in query sequence: %u", (unsigned)(v >> 60));
-            }
-            uint8_t *dst = row + w * 12;
-            for (int i = 0; i < 12; i++) dst[i] = onehot.t[(v >> (5 * i)) & 31u];
+            uint8_t worst = 0;
+            for (uint64_t i = 0; i < L; i++) worst = row[i] > worst ? row[i] : worst;
+            if (worst > 4 && bad_symbol[si] < 0) bad_symbol[si] = worst == 254 ? 0 : 31;
         }
+    };
+    if (spans.size() > 1) {
+        std::vector<std::thread> pool;
+        for (size_t si = 0; si < spans.size(); si++) pool.emplace_back(decode, si);
+        for (auto &th : pool) th.join();
+    } else {
+        decode(0);
     }
-    if (pos >= len) {
-        free(wide);
-        return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
-    }
-    const uint8_t tag = p[pos++];
-    uint64_t L = 0;
-    if (tag == 1) {
-        if (!get_varint(p, len, pos, 10, L) || L == 0) {
+    for (int b : bad_symbol)
+        if (b >= 0) {
             free(wide);
-            return set_error(SMAFA_ERR_FORMAT, "DeserializeBadEncoding");
+            return set_error(SMAFA_ERR_PANIC, "Invalid character in query sequence: %u", (unsigned)b);
         }
-    } else if (tag != 0) {
-        free(wide);
-        return set_error(SMAFA_ERR_FORMAT, "DeserializeBadOption");
-    }
-    if (cnt && (L == 0 || (L + 11) / 12 != nw || L > 0xffffffffull)) {
-        free(wide);
-        return set_error(SMAFA_ERR_FORMAT, "%s: sequence length does not match the window size", path);
-    }
-    // columns < L must hold a symbol (the reference's get_as_string panics otherwise); slots past L are ignored
     uint8_t *out = wide;
-    for (uint64_t j = 0; j < cnt; j++) {
-        const uint8_t *row = wide + (size_t)j * stride;
-        uint8_t worst = 0;
-        for (uint64_t i = 0; i < L; i++) worst = row[i] > worst ? row[i] : worst;
-        if (worst > 4) {
-            unsigned bad = 0;
-            for (uint64_t i = 0; i < L; i++)
-                if (row[i] > 4) {
-                    bad = row[i] == 254 ? 0u : 31u;
-                    break;
-                }
-            free(wide);
-            return set_error(SMAFA_ERR_PANIC, "Invalid character in query sequence: %u", bad);
-        }
-        if (stride != L) memmove(out + (size_t)j * L, row, L);  // compact in place (L < stride, ascending j)
-    }
-    if (!out) out = (uint8_t *)malloc(1);
+    if (stride != L)  // compact in place (L < stride, ascending rows)
+        for (uint64_t j = 0; j < cnt; j++) memmove(out + (size_t)j * L, wide + (size_t)j * stride, L);
     *alphabet = SMAFA_ALPHABET_NT;
     *codes = out;
     *n = cnt;

@@ -143,23 +143,18 @@ int smafa_fastx_load(const char *path, int alphabet, uint8_t **codes_out, uint64
     *codes_out = nullptr;
     *n_out = 0;
     *seq_len = 0;
-    FastxReader reader;
-    int rc = reader.open(path);
+    BulkRecords recs;
+    int rc = load_records_bulk(path, alphabet, false, recs);
     if (rc) return rc;
-    std::vector<uint8_t> codes;
-    uint64_t n = 0;
-    size_t L = 0;
-    FastxRecord rec;
-    while ((rc = reader.next(rec)) == 1) {
-        int erc = encode_record(alphabet, rec, codes);
-        if (erc) return erc;
-        if (n == 0) L = rec.seq_len;
-        else if (rec.seq_len != L)
-            return set_error(SMAFA_ERR_PANIC, "Cannot compute distances between seq of length %zu and windows of lengths %zu",
-                             rec.seq_len, L);
-        n++;
-    }
-    if (rc < 0) return rc;
+    if (recs.err_kind == 1) return set_error(SMAFA_ERR_PANIC, "%s", recs.err_msg.c_str());
+    if (recs.err_kind == 2)
+        return set_error(SMAFA_ERR_PANIC, "Cannot compute distances between seq of length %zu and windows of lengths %zu",
+                         recs.err_len, recs.L);
+    if (recs.err_kind == 3) return set_error(SMAFA_ERR_PANIC, "Cannot add empty sequence to WindowSet");
+    if (recs.err_kind == 4) return set_error(SMAFA_ERR_FORMAT, "%s", recs.err_msg.c_str());
+    std::vector<uint8_t> &codes = recs.codes;
+    const uint64_t n = recs.n;
+    const size_t L = recs.L;
     uint8_t *out = (uint8_t *)malloc(codes.empty() ? 1 : codes.size());
     if (!out) return set_error(SMAFA_ERR_IO, "out of memory");
     if (!codes.empty()) memcpy(out, codes.data(), codes.size());
@@ -174,26 +169,17 @@ int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet) {
     if (!subject_fasta || !db_path) return set_error(SMAFA_ERR_INVALID, "smafa_makedb: NULL path");
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
-    FastxReader reader;
-    int rc = reader.open(subject_fasta);  // src/lib.rs:143-144
+    BulkRecords recs;
+    int rc = load_records_bulk(subject_fasta, alphabet, false, recs);  // src/lib.rs:143-152
     if (rc) return rc;
-    std::vector<uint8_t> codes;
-    uint64_t n = 0;
-    size_t L = 0;
-    FastxRecord rec;
-    while ((rc = reader.next(rec)) == 1) {
-        if (n == 0) {
-            if (rec.seq_len == 0)  // src/lib.rs:103-108
-                return set_error(SMAFA_ERR_PANIC, "Cannot add empty sequence to WindowSet");
-            L = rec.seq_len;
-        }
-        int erc = encode_record(alphabet, rec, codes);  // src/lib.rs:150 — encoding comes before the length check
-        if (erc) return erc;
-        if (rec.seq_len != L)  // src/lib.rs:92-101
-            return set_error(SMAFA_ERR_PANIC, "WindowSet seq length is %zu, got a new sequence of length %zu", L, rec.seq_len);
-        n++;
-    }
-    if (rc < 0) return rc;
+    if (recs.err_kind == 3) return set_error(SMAFA_ERR_PANIC, "Cannot add empty sequence to WindowSet");  // src/lib.rs:103-108
+    if (recs.err_kind == 1) return set_error(SMAFA_ERR_PANIC, "%s", recs.err_msg.c_str());                  // src/lib.rs:38-41
+    if (recs.err_kind == 2)  // src/lib.rs:92-101
+        return set_error(SMAFA_ERR_PANIC, "WindowSet seq length is %zu, got a new sequence of length %zu", recs.L, recs.err_len);
+    if (recs.err_kind == 4) return set_error(SMAFA_ERR_FORMAT, "%s", recs.err_msg.c_str());
+    std::vector<uint8_t> &codes = recs.codes;
+    const uint64_t n = recs.n;
+    const size_t L = recs.L;
     if (L > 0xffffffffull) return set_error(SMAFA_ERR_INVALID, "sequence too long");
     log_line(1, "Encoding of %llu sequences complete, writing db file %s", (unsigned long long)n, db_path);  // src/lib.rs:154-158
     rc = smafa_dbfile_write(db_path, alphabet, codes.data(), n, (uint32_t)L);  // src/lib.rs:161-162
@@ -337,47 +323,34 @@ int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, 
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
     const double t_start = now_seconds();
-    FastxReader reader;
-    int rc = reader.open(input_fasta);  // src/cluster.rs:28
-    if (rc) return rc;
+    int rc = SMAFA_OK;
     log_line(1, "Clustering ..");  // src/cluster.rs:33
 
-    std::vector<uint8_t> raw, codes;
-    uint64_t n = 0;
-    size_t L = 0;
+    BulkRecords recs;
+    rc = load_records_bulk(input_fasta, alphabet, true, recs);  // src/cluster.rs:28,35-43 for every record
+    if (rc) return rc;
+    std::vector<uint8_t> &raw = recs.raw, &codes = recs.codes;
+    const uint64_t n = recs.n;
+    const size_t L = recs.L;
+    if (n >= 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many records");
+    // the record that stopped the load fails AFTER the lines of the records before it have been written
     int pending = SMAFA_OK;
     std::string pending_msg;
-    FastxRecord rec;
-    while ((rc = reader.next(rec)) == 1) {
-        int erc = encode_record(alphabet, rec, codes);  // src/cluster.rs:42-43
-        if (erc) {
-            pending = erc;
-            pending_msg = smafa_last_error();
-            break;
-        }
-        if (n == 0) {
-            if (rec.seq_len == 0) {  // first record becomes a centroid: push_encoding, src/lib.rs:103-108
-                pending = SMAFA_ERR_PANIC;
-                pending_msg = "Cannot add empty sequence to WindowSet";
-                break;
-            }
-            L = rec.seq_len;
-        } else if (rec.seq_len != L) {  // get_distances, src/lib.rs:72-79
-            codes.resize(codes.size() - rec.seq_len);
-            pending = SMAFA_ERR_PANIC;
-            char msg[160];
-            snprintf(msg, sizeof msg, "Cannot compute distances between seq of length %zu and windows of lengths %zu",
-                     rec.seq_len, L);
-            pending_msg = msg;
-            break;
-        }
-        raw.insert(raw.end(), rec.seq, rec.seq + rec.seq_len);
-        n++;
-        if (n >= 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many records");
-    }
-    if (rc < 0 && pending == SMAFA_OK) {
-        pending = rc;
-        pending_msg = smafa_last_error();
+    if (recs.err_kind == 1) {  // src/lib.rs:38-41
+        pending = SMAFA_ERR_PANIC;
+        pending_msg = recs.err_msg;
+    } else if (recs.err_kind == 3) {  // first record becomes a centroid: push_encoding, src/lib.rs:103-108
+        pending = SMAFA_ERR_PANIC;
+        pending_msg = "Cannot add empty sequence to WindowSet";
+    } else if (recs.err_kind == 2) {  // get_distances, src/lib.rs:72-79
+        char msg[160];
+        snprintf(msg, sizeof msg, "Cannot compute distances between seq of length %zu and windows of lengths %zu",
+                 recs.err_len, L);
+        pending = SMAFA_ERR_PANIC;
+        pending_msg = msg;
+    } else if (recs.err_kind == 4) {
+        pending = SMAFA_ERR_FORMAT;
+        pending_msg = recs.err_msg;
     }
 
     if (n > 0) {

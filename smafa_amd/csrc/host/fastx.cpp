@@ -28,21 +28,40 @@ int FastxReader::open(const char *path) {
         return set_error(SMAFA_ERR_FORMAT, "%s: bzip2 input is not supported by this build", path);
     if (got >= 6 && magic[0] == 0xfd && magic[1] == '7' && magic[2] == 'z' && magic[3] == 'X' && magic[4] == 'Z')
         return set_error(SMAFA_ERR_FORMAT, "%s: xz input is not supported by this build", path);
-    gzFile g = gzopen(path, "rb");  // reads plain files unchanged
-    if (!g) return set_error(SMAFA_ERR_IO, "%s: cannot open", path);
-    gzbuffer(g, 1u << 20);
     data_.clear();
-    std::vector<uint8_t> chunk(8u << 20);
-    for (;;) {
-        const int r = gzread(g, chunk.data(), (unsigned)chunk.size());
-        if (r < 0) {
-            gzclose(g);
-            return set_error(SMAFA_ERR_IO, "%s: read error", path);
+    const bool gz = got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    if (!gz) {  // plain file: one read into a buffer of the file's size
+        f = fopen(path, "rb");
+        if (!f) return set_error(SMAFA_ERR_IO, "%s: cannot open", path);
+        if (fseek(f, 0, SEEK_END) == 0) {
+            const long sz = ftell(f);
+            if (sz > 0) data_.resize((size_t)sz);
+            rewind(f);
         }
-        if (r == 0) break;
-        data_.insert(data_.end(), chunk.begin(), chunk.begin() + r);
+        size_t have = data_.empty() ? 0 : fread(data_.data(), 1, data_.size(), f);
+        data_.resize(have);
+        std::vector<uint8_t> more(1u << 20);  // whatever a growing or unseekable file still has
+        size_t r;
+        while ((r = fread(more.data(), 1, more.size(), f)) > 0) data_.insert(data_.end(), more.begin(), more.begin() + r);
+        const bool bad = ferror(f);
+        fclose(f);
+        if (bad) return set_error(SMAFA_ERR_IO, "%s: read error", path);
+    } else {
+        gzFile g = gzopen(path, "rb");
+        if (!g) return set_error(SMAFA_ERR_IO, "%s: cannot open", path);
+        gzbuffer(g, 1u << 20);
+        std::vector<uint8_t> chunk(8u << 20);
+        for (;;) {
+            const int r = gzread(g, chunk.data(), (unsigned)chunk.size());
+            if (r < 0) {
+                gzclose(g);
+                return set_error(SMAFA_ERR_IO, "%s: read error", path);
+            }
+            if (r == 0) break;
+            data_.insert(data_.end(), chunk.begin(), chunk.begin() + r);
+        }
+        gzclose(g);
     }
-    gzclose(g);
     if (data_.empty()) return set_error(SMAFA_ERR_FORMAT, "valid path/file expected: %s is empty", path);
     if (data_[0] != '>' && data_[0] != '@')
         return set_error(SMAFA_ERR_FORMAT, "valid path/file expected: %s does not start with '>' or '@'", path);
@@ -115,6 +134,239 @@ int FastxReader::next(FastxRecord &rec) {
     rec.seq = seq_.data();
     rec.seq_len = seq_.size() - 1;
     return 1;
+}
+
+}  // namespace smafa
+
+// ---------------------------------------------------------------------------------------------- bulk loading
+#include <algorithm>
+#include <thread>
+
+namespace smafa {
+
+namespace {
+
+struct ChunkResult {
+    uint64_t n_records = 0;   // records that start in the chunk
+    uint64_t good = 0;        // parsed without error, in order
+    int err_kind = 0;
+    size_t err_len = 0;
+    std::string err_msg;
+};
+
+// parse the records starting in [lo, hi) of a FASTA buffer into rows first_row.. of codes/raw
+void parse_fasta_chunk(const uint8_t *d, size_t n, size_t lo, size_t hi, int alphabet, size_t L, uint64_t first_row,
+                       uint8_t *codes, uint8_t *raw, ChunkResult &res) {
+    std::vector<uint8_t> seq;
+    size_t p = lo;
+    uint64_t row = first_row;
+    auto eol = [&](size_t from) {
+        const void *q = from < n ? memchr(d + from, '\n', n - from) : nullptr;
+        return q ? (size_t)((const uint8_t *)q - d) : n;
+    };
+    while (p < hi) {
+        // p is at a '>' that begins a line
+        const size_t hs = p + 1, he = eol(hs);
+        size_t id_len = he - hs;
+        if (id_len && d[hs + id_len - 1] == '\r') id_len--;
+        size_t q = he < n ? he + 1 : n;
+        const uint8_t *s;
+        size_t slen;
+        const size_t le0 = eol(q);
+        const size_t q2 = le0 < n ? le0 + 1 : n;
+        if ((q2 >= n || d[q2] == '>') && !(le0 > q && memchr(d + q, '\r', le0 - q))) {
+            s = d + q;  // one sequence line, no CR: in place
+            slen = le0 - q;
+            q = q2;
+        } else {
+            seq.clear();
+            while (q < n && d[q] != '>') {
+                const size_t le = eol(q);
+                for (size_t i = q; i < le; i++)
+                    if (d[i] != '\r') seq.push_back(d[i]);
+                q = le < n ? le + 1 : n;
+            }
+            s = seq.data();
+            slen = seq.size();
+        }
+        // encode first (src/lib.rs:150,235: from_bytes runs before any length check), into a scratch row if the
+        // length is wrong so that a bad byte in an over-long record is still reported
+        uint8_t *crow = codes + (size_t)row * L;
+        for (size_t i = 0; i < slen; i++) {
+            const uint8_t c = code_of(alphabet, s[i]);
+            if (c == 255) {
+                char msg[512];
+                snprintf(msg, sizeof msg, "Byte %u cannot be interpreted as %s, in sequence \"%.*s\" at position %zu", s[i],
+                         alphabet_noun(alphabet), (int)std::min<size_t>(id_len, 300), (const char *)(d + hs), i);
+                res.err_kind = 1;
+                res.err_msg = msg;
+                return;
+            }
+            if (i < L) crow[i] = c;
+        }
+        if (slen != L) {
+            res.err_kind = 2;
+            res.err_len = slen;
+            return;
+        }
+        if (raw) memcpy(raw + (size_t)row * L, s, L);
+        row++;
+        res.good++;
+        p = q;
+        while (p < hi && (d[p] == '\n' || d[p] == '\r')) p++;  // blank lines between records
+        if (p < hi && d[p] != '>') {
+            res.err_kind = 4;
+            res.err_msg = "record does not start with '>'";
+            return;
+        }
+    }
+}
+
+}  // namespace
+
+int load_records_bulk(const char *path, int alphabet, bool want_raw, BulkRecords &out) {
+    out = BulkRecords();
+    FastxReader reader;
+    int rc = reader.open(path);
+    if (rc) return rc;
+    const std::vector<uint8_t> &data = reader.buffer();
+    const uint8_t *d = data.data();
+    const size_t n = data.size();
+    unsigned n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (reader.is_fastq() || n < (32u << 20) || n_threads < 2) {
+        // sequential path: FastxReader record by record
+        FastxRecord rec;
+        while ((rc = reader.next(rec)) == 1) {
+            if (out.n == 0) {
+                out.L = rec.seq_len;
+            }
+            const size_t base = out.codes.size();
+            out.codes.resize(base + rec.seq_len);
+            for (size_t i = 0; i < rec.seq_len; i++) {
+                const uint8_t c = code_of(alphabet, rec.seq[i]);
+                if (c == 255) {
+                    out.codes.resize(base);
+                    char msg[512];
+                    snprintf(msg, sizeof msg, "Byte %u cannot be interpreted as %s, in sequence \"%.*s\" at position %zu",
+                             rec.seq[i], alphabet_noun(alphabet), (int)std::min<size_t>(rec.id_len, 300), (const char *)rec.id, i);
+                    out.err_kind = 1;
+                    out.err_msg = msg;
+                    return SMAFA_OK;
+                }
+                out.codes[base + i] = c;
+            }
+            if (out.n == 0 && rec.seq_len == 0) {
+                out.codes.resize(base);
+                out.err_kind = 3;
+                return SMAFA_OK;
+            }
+            if (rec.seq_len != out.L) {
+                out.codes.resize(base);
+                out.err_kind = 2;
+                out.err_len = rec.seq_len;
+                return SMAFA_OK;
+            }
+            if (want_raw) out.raw.insert(out.raw.end(), rec.seq, rec.seq + rec.seq_len);
+            out.n++;
+        }
+        if (rc < 0) {
+            out.err_kind = 4;
+            out.err_msg = smafa_last_error();
+        }
+        return SMAFA_OK;
+    }
+    // parallel path (plain FASTA): the first record fixes L
+    {
+        FastxRecord rec;
+        rc = reader.next(rec);
+        if (rc < 0) {
+            out.err_kind = 4;
+            out.err_msg = smafa_last_error();
+            return SMAFA_OK;
+        }
+        if (rc == 0) return SMAFA_OK;
+        out.L = rec.seq_len;
+        if (rec.seq_len == 0) {
+            // still report a bad byte first?  an empty sequence has none
+            out.err_kind = 3;
+            return SMAFA_OK;
+        }
+    }
+    const size_t L = out.L;
+    // chunk boundaries snapped forward to the next record start ('>' after '\n')
+    std::vector<size_t> bounds(n_threads + 1, n);
+    bounds[0] = 0;
+    for (unsigned t = 1; t < n_threads; t++) {
+        size_t p = (size_t)((unsigned __int128)n * t / n_threads);
+        while (true) {
+            const void *q = p < n ? memchr(d + p, '>', n - p) : nullptr;
+            if (!q) {
+                p = n;
+                break;
+            }
+            p = (size_t)((const uint8_t *)q - d);
+            if (p == 0 || d[p - 1] == '\n') break;
+            p++;
+        }
+        bounds[t] = p;
+    }
+    for (unsigned t = 1; t <= n_threads; t++) bounds[t] = std::max(bounds[t], bounds[t - 1]);
+    // pass 1: count record starts per chunk
+    std::vector<ChunkResult> res(n_threads);
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_threads; t++)
+            pool.emplace_back([&, t] {
+                uint64_t c = 0;
+                size_t p = bounds[t];
+                const size_t hi = bounds[t + 1];
+                while (p < hi) {
+                    const void *q = memchr(d + p, '>', hi - p);
+                    if (!q) break;
+                    p = (size_t)((const uint8_t *)q - d);
+                    if (p == 0 || d[p - 1] == '\n') c++;
+                    p++;
+                }
+                res[t].n_records = c;
+            });
+        for (auto &th : pool) th.join();
+    }
+    uint64_t total = 0;
+    std::vector<uint64_t> first_row(n_threads);
+    for (unsigned t = 0; t < n_threads; t++) {
+        first_row[t] = total;
+        total += res[t].n_records;
+    }
+    out.codes.resize((size_t)total * L);
+    if (want_raw) out.raw.resize((size_t)total * L);
+    // pass 2: parse + encode
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_threads; t++)
+            pool.emplace_back([&, t] {
+                size_t lo = bounds[t];
+                while (lo < bounds[t + 1] && (d[lo] == '\n' || d[lo] == '\r')) lo++;
+                if (lo < bounds[t + 1])
+                    parse_fasta_chunk(d, n, lo, bounds[t + 1], alphabet, L, first_row[t], out.codes.data(),
+                                      want_raw ? out.raw.data() : nullptr, res[t]);
+            });
+        for (auto &th : pool) th.join();
+    }
+    // first error in file order decides
+    uint64_t good = 0;
+    for (unsigned t = 0; t < n_threads; t++) {
+        good += res[t].good;
+        if (res[t].err_kind) {
+            out.err_kind = res[t].err_kind;
+            out.err_len = res[t].err_len;
+            out.err_msg = res[t].err_msg;
+            break;
+        }
+    }
+    out.n = good;
+    out.codes.resize((size_t)good * L);
+    if (want_raw) out.raw.resize((size_t)good * L);
+    return SMAFA_OK;
 }
 
 }  // namespace smafa

@@ -22,6 +22,9 @@ class FastxReader {
     int open(const char *path);
     // 1 = record, 0 = end of input, negative = error code
     int next(FastxRecord &rec);
+    // the whole (decompressed) input and its format, for the bulk loader
+    const std::vector<uint8_t> &buffer() const { return data_; }
+    bool is_fastq() const { return fastq_; }
 
   private:
     std::vector<uint8_t> data_;
@@ -30,5 +33,26 @@ class FastxReader {
     bool fastq_ = false;
     std::string path_;
 };
+
+}  // namespace smafa
+
+namespace smafa {
+
+// Bulk load of a FASTA/FASTQ(+gzip) file of equal-length records into code rows (and optionally the raw sequence
+// bytes, for cluster's first output column).  Large plain-FASTA inputs are parsed by several threads — a record
+// starts at every '>' that begins a line, so the split is unambiguous — everything else goes through FastxReader.
+// Stops at the FIRST offending record in file order, exactly where the sequential reader would:
+//   err_kind 0 none | 1 byte outside the alphabet (err_msg = the reference's panic text) | 2 length differs from
+//   the first record's (err_len = its length) | 3 the first record is empty | 4 parse error (err_msg)
+// Records before it are complete in codes/raw (n of them).
+struct BulkRecords {
+    std::vector<uint8_t> codes, raw;
+    uint64_t n = 0;
+    size_t L = 0;
+    int err_kind = 0;
+    size_t err_len = 0;
+    std::string err_msg;
+};
+int load_records_bulk(const char *path, int alphabet, bool want_raw, BulkRecords &out);
 
 }  // namespace smafa
