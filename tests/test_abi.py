@@ -200,3 +200,33 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     r = subprocess.run([str(exe), str(tmp_path / "t.db")], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "abi ok" in r.stdout
+
+
+def test_parallel_ingest_paths_match_oracle(tmp_path):
+    """inputs big enough for the multi-threaded FASTA loader (>= 32 MB) and DB decode/serialise (>= 2^20 rows):
+    DB bytes equal the oracle's sequential makedb, decode round-trips, first-error semantics are the oracle's"""
+    from smafa_amd import synth
+    n, L = 1_150_000, 29                      # 29: not a multiple of 12, so rows are compacted after decode
+    codes = synth.subjects(n, L, 0, seed=9, n_frac=0.01)
+    f = str(tmp_path / "big.fna")
+    synth.write_fasta(f, codes, 0)
+    assert os.path.getsize(f) >= 32 << 20
+    a, b = str(tmp_path / "a.db"), str(tmp_path / "b.db")
+    smafa_amd.makedb(f, a)
+    assert oracle.run_cli("makedb", "-i", f, "-d", b).returncode == 0
+    assert open(a, "rb").read() == open(b, "rb").read()
+    alphabet, back = smafa_amd.read_db(a)
+    assert alphabet == 0 and (back == codes).all()
+    assert (smafa_amd.load_fastx(f, 0) == codes).all()
+    # a bad byte and, later, a short record: the FIRST offending record in file order is reported
+    raw = open(f, "rb").read()
+    i = raw.index(b">r900000\n") + len(b">r900000\n")
+    j = raw.index(b">r1100000\n") + len(b">r1100000\n")
+    broken = raw[:i + 3] + b"!" + raw[i + 4:j] + raw[j + 2:]
+    g = str(tmp_path / "broken.fna")
+    open(g, "wb").write(broken)
+    r = cli("makedb", "-i", g, "-d", str(tmp_path / "x.db"))
+    o = oracle.run_cli("makedb", "-i", g, "-d", str(tmp_path / "y.db"))
+    assert r.returncode == o.returncode == 101
+    assert 'Byte 33 cannot be interpreted as nucleotide, in sequence "r900000" at position 3' in r.stderr
+    assert r.stderr.strip().splitlines()[-1] == o.stderr.strip().splitlines()[-1]
