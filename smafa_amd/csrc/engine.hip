@@ -79,6 +79,7 @@ struct smafa_db {
     // scratch of the host-buffer API, kept across calls
     DevBuf upload;            // staging for code rows on their way to the pack kernel
     DevBuf hits, count;       // rows and their counter
+    DevBuf shard_rows, shard_counts;  // where the scan kernels append (kShards segments) before compaction
     DevBuf keys_a, keys_b, sort_tmp;
     smafa_qset scratch_q;     // query set of smafa_scan_hits / smafa_distances
     size_t tile_words() const { return (size_t)P * W * kWaveTile; }
@@ -271,8 +272,8 @@ static uint32_t choose_query_block(const smafa_db *db, uint32_t n_wg_tiles, uint
 
 // one kernel launch: queries [q_begin, q_end) x wave tiles [tile_begin, tile_end)
 static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t tile_begin,
-                        uint32_t tile_end, uint32_t k_tight, uint32_t thr0, smafa_hit *d_hits, uint64_t cap,
-                        unsigned long long *d_count) {
+                        uint32_t tile_end, uint32_t k_tight, uint32_t thr0, smafa_hit *d_shards, uint64_t shard_cap,
+                        unsigned long long *d_shard_counts) {
     ScanArgs a;
     const bool specialised = db->W <= 4;  // else scan_generic_kernel
     const bool lazy = specialised && use_lazy(db, thr0);
@@ -290,9 +291,9 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     a.cnt_stride = db->L + 1;
     a.k_tight = k_tight;
     a.use_filter = db->use_filter ? 1u : 0u;
-    a.hits = d_hits;
-    a.cap = cap;
-    a.count = d_count;
+    a.hits = d_shards;
+    a.shard_cap = shard_cap;
+    a.count = d_shard_counts;
     const uint64_t n_qblocks = (q_end - q_begin + a.qb_size - 1) / a.qb_size;
     const uint64_t grid = n_qblocks * a.n_wg_tiles;
     if (grid > 0x7fffffffull)
@@ -315,10 +316,21 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
 static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t max_div,
                       uint32_t k_tight, smafa_hit *d_hits, uint64_t cap, unsigned long long *d_count) {
     const uint32_t nq = q_end - q_begin;
-    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), db->stream));
     db->last_launches = 0;
     db->timed = false;
-    if (nq == 0 || db->n == 0) return SMAFA_OK;
+    if (nq == 0 || db->n == 0) {
+        HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), db->stream));
+        return SMAFA_OK;
+    }
+    // the kernels append into kShards segments of a scratch block (twice the caller's capacity, so that an uneven
+    // spread over the segments does not look like an overflow); compact_rows_kernel gathers them at the end
+    const uint64_t shard_cap = (2 * cap + kShards - 1) / kShards + 256;
+    int src = db->shard_rows.ensure(shard_cap * kShards * sizeof(smafa_hit));
+    if (!src) src = db->shard_counts.ensure(kShards * sizeof(unsigned long long));
+    if (src) return src;
+    smafa_hit *d_shards = db->shard_rows.as<smafa_hit>();
+    unsigned long long *d_shard_counts = db->shard_counts.as<unsigned long long>();
+    HIP_TRY(hipMemsetAsync(d_shard_counts, 0, kShards * sizeof(unsigned long long), db->stream));
     const uint32_t thr0 = std::min<uint32_t>(max_div, db->L);  // a distance never exceeds seq_len
     if (k_tight)
         hipLaunchKernelGGL(fill_u32_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream,
@@ -336,25 +348,28 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     HIP_TRY(hipEventRecord(db->ev0, db->stream));
     int rc = SMAFA_OK;
     if (k_tight == 0) {
-        rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, thr0, d_hits, cap, d_count);
+        rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, thr0, d_shards, shard_cap, d_shard_counts);
     } else {
         rc = zero_cnt();
         // seed: k = 1 reduces each wave's minimum before its single atomicMin, so a whole workgroup tile is
         // cheap; the k >= 2 seed counts every pair in its histogram, so keep it to one wave tile
         const uint32_t seed_tiles = std::min<uint32_t>(k_tight == 1 ? kWgWaves : 1, n_tiles);
-        if (!rc) rc = launch_tiles(db, qs, q_begin, q_end, 0, seed_tiles, k_tight, thr0, nullptr, 0, d_count);
+        if (!rc) rc = launch_tiles(db, qs, q_begin, q_end, 0, seed_tiles, k_tight, thr0, nullptr, 0, d_shard_counts);
         if (!rc) rc = zero_cnt();  // the seed's subjects are counted again below
         uint32_t begin = 0, len = kWgWaves;
         while (!rc && begin < n_tiles) {
             const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)begin + len, n_tiles);
-            rc = launch_tiles(db, qs, q_begin, q_end, begin, end, k_tight, thr0, d_hits, cap, d_count);
+            rc = launch_tiles(db, qs, q_begin, q_end, begin, end, k_tight, thr0, d_shards, shard_cap, d_shard_counts);
             begin = end;
             len = len > (1u << 28) ? len : len * 8;
         }
     }
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(db->ev1, db->stream));
+    HIP_TRY(hipEventRecord(db->ev1, db->stream));  // smafa_last_scan_ms: the scan kernels, not the gather below
     db->timed = true;
+    hipLaunchKernelGGL(compact_rows_kernel, dim3(kShards), dim3(256), 0, db->stream, d_shards, d_shard_counts,
+                       (unsigned long long)shard_cap, d_hits, (unsigned long long)cap, d_count);
+    HIP_TRY(hipGetLastError());
     return SMAFA_OK;
 }
 
@@ -596,7 +611,7 @@ void smafa_db_destroy(smafa_db *db) {
     if (!db) return;
     (void)hipSetDevice(db->device);
     if (db->d_planes) (void)hipFree(db->d_planes);
-    for (DevBuf *b : {&db->upload, &db->hits, &db->count, &db->keys_a, &db->keys_b, &db->sort_tmp, &db->scratch_q.qrec,
+    for (DevBuf *b : {&db->upload, &db->hits, &db->count, &db->shard_rows, &db->shard_counts, &db->keys_a, &db->keys_b, &db->sort_tmp, &db->scratch_q.qrec,
                       &db->scratch_q.thr, &db->scratch_q.cnt})
         b->release();
     if (db->ev0) (void)hipEventDestroy(db->ev0);

@@ -44,6 +44,7 @@ namespace smafa {
 constexpr int kWaveTile = 256;  // subjects per wave tile
 constexpr int kWgWaves = 4;     // waves per workgroup
 constexpr int kChunk = 64;      // queries staged in LDS at a time
+constexpr uint32_t kShards = 64;  // row-append segments (and counters) per scan
 // __launch_bounds__ second argument (waves per SIMD the register budget must allow) for the scan kernel:
 // the subject words held per lane plus ~40 working registers, mapped through the gfx950 allocation steps.
 __host__ __device__ constexpr int scan_min_waves(int ps, int w, int t) {
@@ -81,9 +82,12 @@ struct ScanArgs {
     uint32_t cnt_stride;
     uint32_t k_tight;         // 0: bounds fixed; 1: lower to running minimum; k>=2: lower to running k-th
     uint32_t use_filter;      // 0: always the full comparison; 1: prefilter with per-wave fallback
+    // Row append, sharded: workgroup b appends to segment b % kShards of `hits` (shard_cap rows each) through
+    // counter count[b % kShards] — one global counter saturates near 80 M appends/s, which is what a dense scan
+    // needs per millisecond.  compact_rows_kernel then restores one contiguous list + one count.
     smafa_hit *hits;          // NULL: seed pass — tighten bounds, append nothing
-    unsigned long long cap;
-    unsigned long long *count;
+    unsigned long long shard_cap;
+    unsigned long long *count;  // kShards counters
 };
 
 // acc | (s ^ q) in one VALU op.  Truth table over (a=0xF0, b=0xCC, c=0xAA): 0xF0 | (0xCC ^ 0xAA) = 0xF6.
@@ -107,13 +111,14 @@ __device__ __forceinline__ uint32_t ld_relaxed(const uint32_t *p) {
 // subject within the true bound passes `dist <= thr` whenever it is visited.
 __device__ __forceinline__ void emit(const ScanArgs &a, uint32_t q, uint32_t subject, uint32_t dist) {
     if (a.hits) {
-        unsigned long long slot = atomicAdd(a.count, 1ull);
-        if (slot < a.cap) {
+        const uint32_t shard = blockIdx.x % kShards;
+        unsigned long long slot = atomicAdd(a.count + shard, 1ull);
+        if (slot < a.shard_cap) {
             smafa_hit h;
             h.query = q;
             h.subject = subject;
             h.dist = dist;
-            a.hits[slot] = h;
+            a.hits[(size_t)shard * a.shard_cap + slot] = h;
         }
     }
     if (a.k_tight == 1) {
@@ -773,6 +778,28 @@ __global__ void replane_kernel(const uint32_t *src, uint32_t *dst, uint64_t n_ti
     const uint64_t tile = i / per_tile, r = i % per_tile;
     const uint32_t p = (uint32_t)(r / (W * 256u)), rest = (uint32_t)(r % (W * 256u));
     dst[i] = p < p_old ? src[tile * (uint64_t)p_old * W * 256 + (uint64_t)p * W * 256 + rest] : 0u;
+}
+
+// After a scan: gather the kShards row segments into one contiguous list of at most `cap` rows and publish one
+// count.  If any segment overflowed its shard_cap (rows were dropped) the published count is forced above `cap`,
+// which is the "did not fit, retry" signal of the scan API.  One workgroup per segment.
+__global__ __launch_bounds__(256) void compact_rows_kernel(const smafa_hit *shards, const unsigned long long *counts,
+                                                           unsigned long long shard_cap, smafa_hit *out,
+                                                           unsigned long long cap, unsigned long long *out_count) {
+    const uint32_t s = blockIdx.x;
+    unsigned long long before = 0, total = 0;
+    bool dropped = false;
+    for (uint32_t i = 0; i < kShards; i++) {
+        const unsigned long long c = counts[i];
+        if (c > shard_cap) dropped = true;
+        if (i < s) before += c < shard_cap ? c : shard_cap;
+        total += c;
+    }
+    const unsigned long long mine = counts[s] < shard_cap ? counts[s] : shard_cap;
+    const smafa_hit *src = shards + (size_t)s * shard_cap;
+    for (unsigned long long i = threadIdx.x; i < mine; i += blockDim.x)
+        if (before + i < cap) out[before + i] = src[i];
+    if (s == 0 && threadIdx.x == 0) *out_count = (dropped && total <= cap) ? cap + 1 : total;
 }
 
 __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {
