@@ -290,7 +290,10 @@ def main() -> None:
             "verified": ok,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "smafa::scan_kernel<%d,%d>" % (info.planes, info.words_per_plane),
+                # the instantiation rocprofv3 lists (profiles/r01_d_kernel_stats.csv): <PS, PQ, W, T, SEED>
+                "kernel": "smafa::%s<%d, %d, %d, %d, false>" % (
+                    "scan_lazy_kernel" if plan["filter_plane_resident"] else "scan_kernel", info.planes,
+                    5 if args.alphabet == "aa" else 3, info.words_per_plane, plan["tiles_per_wave"]),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -177,6 +177,21 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
                 uint32_t limit_per_sequence, int out_fd, int device);
 /* cluster(input_fasta, max_divergence, print_stream) — src/cluster.rs:13-94. */
 int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet);
+/* The same clustering spread over `world` processes, one GPU each (cluster mode): every rank reads
+ * the whole input and keeps a replica of the centroid store on its own device; each batch of unseen records is
+ * split into contiguous slices, rank r scans slice r, and the per-record results are exchanged through
+ * `allgather` twice per batch (nearest old centroid: 8 bytes per record; in-range (record, candidate) rows:
+ * 12 bytes each).  Every rank then resolves the batch identically and appends the same new centroids to its
+ * replica — there is no broadcast.  Rank 0 writes the reference's output bytes to out_fd; other ranks write
+ * nothing.  The result does not depend on `world`.
+ * `allgather(ctx, send, send_bytes, &recv, &recv_bytes)` must return 0 and leave in *recv the blocks of ALL
+ * ranks concatenated in rank order (block sizes differ between ranks); the buffer stays valid until the next
+ * call.  The library never touches the transport: the caller supplies RCCL (torch.distributed in
+ * smafa_amd/dist.py), MPI, ... */
+typedef int (*smafa_allgather_fn)(void *ctx, const void *send, uint64_t send_bytes, const void **recv,
+                                  uint64_t *recv_bytes);
+int smafa_cluster_sharded(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet,
+                          uint32_t rank, uint32_t world, smafa_allgather_fn allgather, void *ctx);
 /* count(paths) — src/lib.rs:378-398 (JSON to out_fd).  Host only. */
 int smafa_count(const char *const *paths, uint64_t n_paths, int out_fd);
 

@@ -27,8 +27,12 @@ EXPORTS = [
     "smafa_scan_hits", "smafa_distances", "smafa_qset_create", "smafa_qset_destroy", "smafa_scan_launch",
     "smafa_sync", "smafa_last_scan_ms", "smafa_last_scan_plan", "smafa_set_query_block", "smafa_set_prefilter", "smafa_select_rows",
     "smafa_dbfile_write", "smafa_dbfile_read", "smafa_fastx_load", "smafa_free",
-    "smafa_makedb", "smafa_query", "smafa_cluster", "smafa_count",
+    "smafa_makedb", "smafa_query", "smafa_cluster", "smafa_cluster_sharded", "smafa_count",
 ]
+
+
+# smafa_allgather_fn: int (*)(void *ctx, const void *send, uint64_t n, const void **recv, uint64_t *recv_n)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64))
 
 
 class Hit(C.Structure):
@@ -100,6 +104,8 @@ def lib() -> C.CDLL:
     l.smafa_makedb.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     l.smafa_query.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
     l.smafa_cluster.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_int]
+    l.smafa_cluster_sharded.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                        ALLGATHER_FN, vp]
     l.smafa_count.argtypes = [C.POINTER(C.c_char_p), C.c_uint64, C.c_int]
     _lib = l
     return l

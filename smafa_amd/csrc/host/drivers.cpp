@@ -318,8 +318,15 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
 //      than new ones, and new ones are numbered in input order, so "smallest distance, then lowest
 //      centroid index" is evaluated exactly as the reference's first-minimum scan (src/cluster.rs:62-68).
 // Nothing is approximated: the result is the reference's, record for record.
-int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet) {
+//
+// Sharded over `world` processes (one GPU each, smafa_cluster_sharded): steps 1 and 2 scan only this rank's
+// contiguous slice of the batch, the slices' results are exchanged through the caller's allgather, and step 3
+// runs identically on every rank, so the replicas of the centroid store stay equal without a broadcast.
+static int cluster_run(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet,
+                       uint32_t rank, uint32_t world, smafa_allgather_fn allgather, void *ctx) {
     if (!input_fasta) return set_error(SMAFA_ERR_INVALID, "smafa_cluster: NULL path");
+    if (world == 0 || rank >= world) return set_error(SMAFA_ERR_INVALID, "rank %u outside world of %u", rank, world);
+    if (world > 1 && !allgather) return set_error(SMAFA_ERR_INVALID, "smafa_cluster_sharded: NULL allgather");
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
     const double t_start = now_seconds();
@@ -383,20 +390,41 @@ int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, 
             const size_t nb = std::min(B, uniq.size() - pos);
             batch_codes.resize(nb * L);
             for (size_t b = 0; b < nb; b++) memcpy(&batch_codes[b * L], &codes[(size_t)uniq[pos + b] * L], L);
+            // this rank's slice of the batch; slices are contiguous and in rank order
+            const size_t s_lo = nb * rank / world, s_hi = nb * (rank + 1) / world, ns = s_hi - s_lo;
 
             // 1. nearest old centroid per record: rows ordered (record, distance, centroid), minimum only
             old_hits.clear();
-            if (!centroid_rec.empty()) {
-                rc = scan_to_host(centroids.db, batch_codes.data(), nb, max_divergence, 1, old_hits);
+            if (!centroid_rec.empty() && ns) {
+                rc = scan_to_host(centroids.db, batch_codes.data() + s_lo * L, ns, max_divergence, 1, old_hits);
                 if (rc) return rc;
+            }
+            std::vector<uint32_t> old_d(nb, UINT32_MAX), old_c(nb, UINT32_MAX);
+            for (size_t t = old_hits.size(); t-- > 0;) {  // backwards: the first row of each record wins
+                old_d[s_lo + old_hits[t].query] = old_hits[t].dist;
+                old_c[s_lo + old_hits[t].query] = old_hits[t].subject;
+            }
+            if (world > 1) {  // exchange (distance, centroid) of every record: nb x 8 bytes
+                std::vector<uint32_t> mine(2 * ns);
+                for (size_t b = 0; b < ns; b++) {
+                    mine[2 * b] = old_d[s_lo + b];
+                    mine[2 * b + 1] = old_c[s_lo + b];
+                }
+                const void *all = nullptr;
+                uint64_t all_bytes = 0;
+                if (allgather(ctx, mine.data(), mine.size() * 4, &all, &all_bytes) != 0)
+                    return set_error(SMAFA_ERR_IO, "allgather failed (nearest old centroids)");
+                if (all_bytes != nb * 8 || (nb && !all))
+                    return set_error(SMAFA_ERR_INVALID, "allgather returned %llu bytes, expected %zu",
+                                     (unsigned long long)all_bytes, nb * 8);
+                const uint32_t *w = (const uint32_t *)all;
+                for (size_t b = 0; b < nb; b++) {
+                    old_d[b] = w[2 * b];
+                    old_c[b] = w[2 * b + 1];
+                }
             }
             t_old += now_seconds() - t0;
             t0 = now_seconds();
-            std::vector<uint32_t> old_d(nb, UINT32_MAX), old_c(nb, UINT32_MAX);
-            for (size_t t = old_hits.size(); t-- > 0;) {  // backwards: the first row of each record wins
-                old_d[old_hits[t].query] = old_hits[t].dist;
-                old_c[old_hits[t].query] = old_hits[t].subject;
-            }
 
             // 2. candidates = records with no old centroid in range
             cand_pos.clear();
@@ -413,8 +441,25 @@ int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, 
                 if (rc) return rc;
                 rc = smafa_db_append(cand.db, cand_codes.data(), cand_pos.size());
                 if (rc) return rc;
-                rc = scan_to_host(cand.db, batch_codes.data(), nb, max_divergence, SMAFA_NONE, cand_hits);
-                if (rc) return rc;
+                if (ns) {
+                    rc = scan_to_host(cand.db, batch_codes.data() + s_lo * L, ns, max_divergence, SMAFA_NONE, cand_hits);
+                    if (rc) return rc;
+                }
+                for (smafa_hit &hrow : cand_hits) hrow.query += (uint32_t)s_lo;  // position in the batch
+                if (world > 1) {  // rows of slice r precede rows of slice r+1: the concatenation stays ordered
+                    const void *all = nullptr;
+                    uint64_t all_bytes = 0;
+                    if (allgather(ctx, cand_hits.data(), cand_hits.size() * sizeof(smafa_hit), &all, &all_bytes) != 0)
+                        return set_error(SMAFA_ERR_IO, "allgather failed (candidate rows)");
+                    if (all_bytes % sizeof(smafa_hit) || (all_bytes && !all))
+                        return set_error(SMAFA_ERR_INVALID, "allgather returned %llu bytes, not whole rows",
+                                         (unsigned long long)all_bytes);
+                    const smafa_hit *rows = (const smafa_hit *)all;
+                    cand_hits.assign(rows, rows + all_bytes / sizeof(smafa_hit));
+                    for (const smafa_hit &hrow : cand_hits)
+                        if (hrow.query >= nb || hrow.subject >= cand_pos.size())
+                            return set_error(SMAFA_ERR_INVALID, "allgather returned a row outside the batch");
+                }
             }
 
             t_cand += now_seconds() - t0;
@@ -457,7 +502,8 @@ int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, 
             t_append += now_seconds() - t0;
             pos += nb;
             // batch size follows the row volume: grow while the scans stay cheap, shrink on dense input
-            const size_t volume = old_hits.size() + cand_hits.size();
+            // (from exchanged quantities only, so every rank takes the same decision)
+            const size_t volume = (nb - cand_pos.size()) + cand_hits.size();
             if (volume < (4u << 20) && B < 65536) B *= 2;
             else if (volume > (16u << 20) && B > 256) B /= 2;
         }
@@ -467,7 +513,7 @@ int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, 
         // src/cluster.rs:79-84
         std::string text;
         text.reserve(1 << 20);
-        for (uint64_t i = 0; i < n; i++) {
+        for (uint64_t i = 0; i < n && rank == 0; i++) {
             if (centroid_of[i] == UINT32_MAX) continue;  // duplicate: no line
             text.append((const char *)&raw[i * L], L);
             text.push_back('\t');
@@ -486,6 +532,15 @@ int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, 
     }
     if (pending != SMAFA_OK) return set_error(pending, "%s", pending_msg.c_str());
     return SMAFA_OK;
+}
+
+int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet) {
+    return cluster_run(input_fasta, max_divergence, out_fd, device, alphabet, 0, 1, nullptr, nullptr);
+}
+
+int smafa_cluster_sharded(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet,
+                          uint32_t rank, uint32_t world, smafa_allgather_fn allgather, void *ctx) {
+    return cluster_run(input_fasta, max_divergence, out_fd, device, alphabet, rank, world, allgather, ctx);
 }
 
 // -------------------------------------------------------------------------------------- count

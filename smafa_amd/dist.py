@@ -1,4 +1,4 @@
-"""Multi-GPU `query`: one process per GPU over torch.distributed (backend "nccl" = RCCL on ROCm).
+"""Multi-GPU `query` and `cluster`: one process per GPU over torch.distributed (backend "nccl" = RCCL on ROCm).
 
 The query loop of the reference carries no state between records except the running query number
 (/root/reference/src/lib.rs:232-318), so queries shard with NO data-path collective: the subject store is
@@ -8,8 +8,15 @@ selects its rows locally, and the only exchange is one gather of the finished ro
 order, so the concatenation is already in the reference's print order; the output is byte-identical for
 any number of ranks.
 
+`cluster` is sequential across records (/root/reference/src/cluster.rs:35-85) but exact in batches: every rank
+keeps a replica of the centroid store, scans its slice of each batch, and two small all-gathers per batch
+(nearest old centroid per record; in-range (record, candidate) rows) give every rank what it needs to resolve
+the batch identically — see smafa_cluster_sharded in include/smafa_amd.h.  The batch logic is the C++ driver's;
+this module only supplies the transport.
+
 Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
              -m smafa_amd.dist query -d DB -q QUERIES [--max-divergence D] [--max-num-hits K] ...
+         python -m torch.distributed.run ... -m smafa_amd.dist cluster -i INPUT -d D [--alphabet aa]
 """
 from __future__ import annotations
 
@@ -65,9 +72,61 @@ def gather_rows(rows: np.ndarray, dist, device=None) -> Optional[np.ndarray]:
     return np.ascontiguousarray(np.concatenate(out, axis=0)).view(api.HIT_DTYPE).reshape(-1)
 
 
+def allgather_bytes(mine: np.ndarray, dist, device=None) -> np.ndarray:
+    """Blocks of bytes of different sizes, one per rank -> their concatenation in rank order, on every rank
+    (sizes first, then the blocks padded to the longest: RCCL has no allgatherv)."""
+    import torch
+
+    world = dist.get_world_size()
+    mine = np.ascontiguousarray(mine, dtype=np.uint8).reshape(-1)
+    count = torch.tensor([len(mine)], dtype=torch.int64, device=device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, count)
+    counts = [int(c.item()) for c in counts]
+    width = max(max(counts), 1)
+    padded = np.zeros(width, dtype=np.uint8)
+    padded[: len(mine)] = mine
+    block = torch.from_numpy(padded).to(device) if device is not None else torch.from_numpy(padded)
+    parts = [torch.zeros_like(block) for _ in range(world)]
+    dist.all_gather(parts, block)
+    return np.concatenate([p.cpu().numpy()[:c] for p, c in zip(parts, counts)])
+
+
+def cluster_sharded(input_fasta: str, max_divergence: int, out_fd: int = 1, alphabet: int = api.ALPHABET_NT,
+                    dist=None, device=None, gpu: Optional[int] = None) -> None:
+    """`smafa cluster` across the ranks of an initialised process group (src/cluster.rs:13-94 semantics; output
+    bytes do not depend on the number of ranks).  Rank 0 writes to out_fd.  `gpu` = HIP device of this rank
+    (default LOCAL_RANK)."""
+    import ctypes as C
+
+    from . import _lib
+
+    if dist is None:
+        import torch.distributed as dist  # type: ignore[no-redef]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    hold = {}
+
+    def gather(ctx, send, n, recv, recv_n):
+        try:
+            mine = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(int(n),)) if n else np.zeros(0, np.uint8)
+            hold["buf"] = out = allgather_bytes(mine, dist, device)  # stays alive until the next call
+            recv[0] = out.ctypes.data if len(out) else None
+            recv_n[0] = len(out)
+            return 0
+        except Exception as e:  # never unwind through the C frames
+            sys.stderr.write("allgather failed on rank %d: %r\n" % (rank, e))
+            return 1
+
+    cb = _lib.ALLGATHER_FN(gather)
+    if gpu is None:
+        gpu = int(os.environ.get("LOCAL_RANK", rank))
+    api.check(_lib.lib().smafa_cluster_sharded(os.fsencode(input_fasta), int(max_divergence), out_fd, gpu, alphabet,
+                                                rank, world, cb, None))
+
+
 def query_sharded(db_path: str, query_fasta: str, max_divergence: Optional[int] = None,
                   max_num_hits: Optional[int] = None, limit_per_sequence: Optional[int] = None, out_fd: int = 1,
-                  scan_fn: Optional[ScanFn] = None, dist=None, device=None) -> None:
+                  scan_fn: Optional[ScanFn] = None, dist=None, device=None, gpu: Optional[int] = None) -> None:
     """`smafa query` across the ranks of an initialised process group (src/lib.rs:198-325 semantics).
 
     `scan_fn(subject_codes, query_codes, max_divergence, k)` must return every row within the bounds ordered
@@ -84,7 +143,7 @@ def query_sharded(db_path: str, query_fasta: str, max_divergence: Optional[int] 
         raise api.SmafaPanic(-6, "Cannot compute distances between seq of length %d and windows of lengths %d"
                              % (queries.shape[1], L))
     if scan_fn is None:
-        scan_fn = HipScanner(alphabet, int(os.environ.get("LOCAL_RANK", rank)))
+        scan_fn = HipScanner(alphabet, int(os.environ.get("LOCAL_RANK", rank)) if gpu is None else gpu)
     lo, hi = shard_bounds(len(queries), world, rank)
     kmode = max_num_hits is not None and max_num_hits != 1
     dev_k = 1 if not kmode else (None if (max_num_hits == 0 or max_num_hits > n) else max_num_hits)
@@ -113,28 +172,51 @@ def _main(argv) -> int:
     import torch.distributed as dist
 
     ap = argparse.ArgumentParser(prog="smafa_amd.dist")
-    ap.add_argument("command", choices=["query"])
-    ap.add_argument("-d", "--database", required=True)
-    ap.add_argument("-q", "--query", required=True)
-    ap.add_argument("--max-divergence", type=int)
-    ap.add_argument("--max-num-hits", type=int)
-    ap.add_argument("--limit-per-sequence", type=int)
-    ap.add_argument("--backend", default="nccl")
+    sub = ap.add_subparsers(dest="command", required=True)
+    q = sub.add_parser("query")  # flags of src/main.rs:64-95
+    q.add_argument("-d", "--database", required=True)
+    q.add_argument("-q", "--query", required=True)
+    q.add_argument("--max-divergence", type=int)
+    q.add_argument("--max-num-hits", type=int)
+    q.add_argument("--limit-per-sequence", type=int)
+    c = sub.add_parser("cluster")  # flags of src/main.rs:96-108
+    c.add_argument("-i", "--input", required=True)
+    c.add_argument("-d", "--max-divergence", type=int, required=True)
+    c.add_argument("--alphabet", choices=["nt", "aa"], default="nt")
+    for p in (q, c):
+        p.add_argument("--backend", default="nccl")
+        p.add_argument("-o", "--output", help="rank 0 writes the rows here instead of stdout")
+        p.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (rehearsals on a 1-GPU box)")
+        p.add_argument("-v", "--verbose", action="store_true", help="rank 0 logs the drivers' debug lines to stderr")
     a = ap.parse_args(argv)
+    if a.verbose and int(os.environ.get("RANK", "0")) == 0:
+        from . import _lib
+        _lib.lib().smafa_set_verbosity(2)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     device = None
     if a.backend == "nccl":
+        local = 0 if a.single_device else local
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
         dist.init_process_group("nccl", device_id=device)
     else:
         dist.init_process_group(a.backend)
+    fd = 1
+    if a.output and int(os.environ.get("RANK", "0")) == 0:
+        fd = os.open(a.output, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
     try:
-        query_sharded(a.database, a.query, a.max_divergence, a.max_num_hits, a.limit_per_sequence, 1, dist=dist, device=device)
+        if a.command == "cluster":
+            cluster_sharded(a.input, a.max_divergence, fd, api.ALPHABET_AA if a.alphabet == "aa" else api.ALPHABET_NT,
+                            dist=dist, device=device, gpu=0 if a.single_device else local)
+        else:
+            query_sharded(a.database, a.query, a.max_divergence, a.max_num_hits, a.limit_per_sequence, fd, dist=dist,
+                          device=device, gpu=0 if a.single_device else local)
     except api.SmafaError as e:
         sys.stderr.write(str(e) + "\n")
         return 101 if isinstance(e, api.SmafaPanic) else 1
     finally:
+        if fd != 1:
+            os.close(fd)
         dist.destroy_process_group()
     return 0
 

@@ -230,3 +230,23 @@ def test_parallel_ingest_paths_match_oracle(tmp_path):
     assert r.returncode == o.returncode == 101
     assert 'Byte 33 cannot be interpreted as nucleotide, in sequence "r900000" at position 3' in r.stderr
     assert r.stderr.strip().splitlines()[-1] == o.stderr.strip().splitlines()[-1]
+
+
+def test_cluster_sharded_argument_checks(tmp_path):
+    """rank/world/transport are validated before anything touches a device"""
+    import ctypes as C
+
+    l = _lib.lib()
+    path = os.fsencode(str(tmp_path / "none.fna"))
+    null_cb = C.cast(None, _lib.ALLGATHER_FN)
+    assert l.smafa_cluster_sharded(path, 3, 1, 0, 0, 2, 2, null_cb, None) == -1
+    assert b"rank 2 outside world of 2" in l.smafa_last_error()
+    assert l.smafa_cluster_sharded(path, 3, 1, 0, 0, 0, 0, null_cb, None) == -1
+    assert l.smafa_cluster_sharded(path, 3, 1, 0, 0, 1, 2, null_cb, None) == -1
+    assert b"NULL allgather" in l.smafa_last_error()
+    # an empty file is a parse error (needletail refuses it) before the transport or a device is touched
+    empty = str(tmp_path / "empty.fna")
+    open(empty, "w").close()
+    calls = []
+    cb = _lib.ALLGATHER_FN(lambda *a: calls.append(a) or 1)
+    assert l.smafa_cluster_sharded(os.fsencode(empty), 3, 1, 0, 0, 1, 2, cb, None) == -5 and not calls

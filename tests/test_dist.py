@@ -39,14 +39,16 @@ def make_inputs(tmp_path, n=600, q=45, L=30):
     return db, qf
 
 
-def run_world(world, db, qf, out, flags, hip=False):
+def launch(world, worker_args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py"), "--db", db, "--queries", qf, "--out", out, *flags]
-    if hip:
-        cmd.append("--hip")
+           os.path.join(ROOT, "tests", "dist_worker.py"), *worker_args]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+
+
+def run_world(world, db, qf, out, flags, hip=False):
+    return launch(world, ["--db", db, "--queries", qf, "--out", out, *flags] + (["--hip"] if hip else []))
 
 
 def test_shard_bounds_cover_everything():
@@ -84,3 +86,55 @@ def test_sharded_query_hip_scanner_equals_oracle(tmp_path):
     r = run_world(2, db, qf, out, flags, hip=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(out).read() == want.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_allgather_bytes_ragged_blocks_gloo(tmp_path, world):
+    """the transport under smafa_cluster_sharded: blocks of different sizes (one empty) in rank order"""
+    out = str(tmp_path / "g")
+    r = launch(world, ["--mode", "gather", "--out", out])
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = []
+    for rnd in range(3):
+        for rank in range(world):
+            size = [rank * 5 + 1, 0 if rank == 0 else 3, 70001][rnd]
+            want.append(((np.arange(size) * 7 + rank * 13 + rnd) % 251).astype(np.uint8))
+    want = np.concatenate(want)
+    for rank in range(world):
+        assert np.array_equal(np.load(out + ".rank%d.npy" % rank), want)
+
+
+def cluster_input(tmp_path, roots=700, members=9, L=60, seed=5):
+    rng = np.random.default_rng(seed)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    base = letters[rng.integers(0, 4, size=(roots, L))]
+    recs = np.repeat(base, members, axis=0)
+    for r in recs:
+        for _ in range(rng.integers(0, 4)):
+            r[rng.integers(0, L)] = letters[rng.integers(0, 4)]
+    recs = recs[rng.permutation(len(recs))]
+    recs[100:130] = recs[7]  # exact duplicates (skipped by the reference, src/cluster.rs:46-48)
+    path = str(tmp_path / "c.fna")
+    oracle.write_fasta(path, [bytes(r) for r in recs])
+    return path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_cluster_equals_oracle_and_single_rank(tmp_path, world):
+    """smafa_cluster_sharded: slices of every batch on different ranks (all on GPU 0 here), two all-gathers per
+    batch, identical sequential pass on every rank — the bytes of the reference's cluster, for any world size"""
+    path = cluster_input(tmp_path)  # 6300 records: several batches (the first holds 1024)
+    want = oracle.run_cli("cluster", "-i", path, "-d", "4")
+    assert want.returncode == 0 and len(want.stdout) > 0
+    out = str(tmp_path / "out.tsv")
+    r = launch(world, ["--mode", "cluster", "--input", path, "--max-divergence", "4", "--out", out])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(out).read() == want.stdout
+    single = str(tmp_path / "single.tsv")
+    fd = os.open(single, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    try:
+        smafa_amd.cluster(path, 4, out_fd=fd)
+    finally:
+        os.close(fd)
+    assert open(single).read() == want.stdout

@@ -12,3 +12,17 @@ dt = time.time() - t
 lines = sum(1 for _ in open("/tmp/cluster.out", "rb"))
 cents = len(set(l.split(b"\t")[1] for l in open("/tmp/cluster.out", "rb")))
 print("cluster rc=%d %.1fs records=%d lines=%d centroids=%d stderr=%s" % (r.returncode, dt, len(recs), lines, cents, r.stderr[-300:]))
+# sharded form: W ranks over gloo, all on GPU 0 of this box (a rehearsal of the exchange, not a speed-up:
+# the ranks share one GPU); the bytes must equal the single-process output
+import hashlib
+want = hashlib.sha256(open("/tmp/cluster.out", "rb").read()).hexdigest()
+for world in [int(w) for w in os.environ.get("SMAFA_WORLDS", "2,4").split(",") if w]:
+    t = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+                        "--master-addr", "127.0.0.1", "--master-port", str(29610 + world), "-m", "smafa_amd.dist",
+                        "cluster", "-i", "/tmp/cluster.faa", "-d", "5", "--alphabet", "aa", "--backend", "gloo",
+                        "--single-device", "-v", "-o", "/tmp/cluster.w.out"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dt = time.time() - t
+    got = hashlib.sha256(open("/tmp/cluster.w.out", "rb").read()).hexdigest()  # -o: gloo's banner goes to stdout
+    print("world=%d rc=%d %.1fs (incl. %d x python+torch start-up) identical=%s %s" % (world, r.returncode, dt, world, got == want, r.stderr[-420:].decode(errors="replace")), flush=True)
