@@ -18,6 +18,8 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div, uint32_t max_num_hits,
                  std::vector<smafa_hit> &out);
 
+// Forget the subjects but keep the handle's device memory, stream and scratch (cluster's per-batch candidate store).
+int db_clear(smafa_db *db);
 // selection rules of src/lib.rs:241-315 (see smafa_select_rows in the public header)
 int select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint64_t n_subjects,
                 const uint8_t *subject_codes, uint32_t seq_len, uint32_t max_div, uint32_t max_num_hits,

@@ -480,6 +480,14 @@ static int collect_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_
     return SMAFA_OK;
 }
 
+// Rows past n in the last tile keep their old bits; every kernel tests subject < n_subjects before it reports or
+// tightens a bound, exactly as it does for the zero padding of a fresh store.
+int db_clear(smafa_db *db) {
+    if (!db) return set_error(SMAFA_ERR_INVALID, "db_clear: NULL handle");
+    db->n = 0;
+    return SMAFA_OK;
+}
+
 int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div,
                  uint32_t max_num_hits, std::vector<smafa_hit> &out) {
     out.clear();

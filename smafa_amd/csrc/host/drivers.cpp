@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../engine.h"
@@ -79,53 +80,66 @@ struct FreeGuard {
     ~FreeGuard() { smafa_free(p); }
 };
 
-// fixed-width row set with open addressing: HashSet<Vec<u64>> of src/cluster.rs:24
-class RowSet {
-  public:
-    RowSet(const uint8_t *rows, uint32_t L) : rows_(rows), L_(L), slots_(1024, UINT32_MAX) {}
-    // true if row `idx` was not present before
-    bool insert(uint32_t idx) {
-        if ((count_ + 1) * 2 > slots_.size()) grow();
-        return put(idx);
+// First occurrences of every distinct row, in input order — the HashSet<Vec<u64>> test of src/cluster.rs:24,46-48.
+// Rows are hashed by all threads, then thread t owns the rows whose hash falls in partition t and runs them, in input
+// order, through its own open-addressing table; "first" is decided inside one partition, so the result does not
+// depend on the number of threads.
+inline uint64_t row_hash(const uint8_t *p, uint32_t L) {
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+    uint32_t i = 0;
+    for (; i + 8 <= L; i += 8) {
+        uint64_t v;
+        memcpy(&v, p + i, 8);
+        h = (h ^ v) * 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
     }
+    for (; i < L; i++) h = (h ^ p[i]) * 0x100000001b3ull;
+    return h ^ (h >> 29);
+}
 
-  private:
-    uint64_t hash(const uint8_t *p) const {
-        uint64_t h = 0x9e3779b97f4a7c15ull;
-        uint32_t i = 0;
-        for (; i + 8 <= L_; i += 8) {
-            uint64_t v;
-            memcpy(&v, p + i, 8);
-            h = (h ^ v) * 0xff51afd7ed558ccdull;
-            h ^= h >> 32;
+void first_occurrences(const uint8_t *rows, uint64_t n, uint32_t L, std::vector<uint32_t> &uniq) {
+    const unsigned T = n >= (1u << 18) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    std::vector<uint64_t> hash(n);
+    std::vector<uint8_t> first(n, 0);
+    auto run = [&](auto &&fn) {
+        if (T == 1) return fn(0u);
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < T; t++) pool.emplace_back(fn, t);
+        for (auto &th : pool) th.join();
+    };
+    run([&](unsigned t) {
+        for (uint64_t i = n * t / T, e = n * (t + 1) / T; i < e; i++) hash[i] = row_hash(rows + i * L, L);
+    });
+    run([&](unsigned t) {
+        auto mine = [&](uint64_t h) { return (unsigned)((h >> 40) % T) == t; };  // slot bits come from the low end
+        size_t count = 0;
+        for (uint64_t i = 0; i < n; i++) count += mine(hash[i]);
+        size_t cap = 16;
+        while (cap < count * 2) cap *= 2;
+        std::vector<uint32_t> slots(cap, UINT32_MAX);
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t h = hash[i];
+            if (!mine(h)) continue;
+            size_t s = h & (cap - 1);
+            bool seen = false;
+            while (slots[s] != UINT32_MAX) {
+                const uint32_t j = slots[s];
+                if (hash[j] == h && memcmp(rows + (size_t)j * L, rows + i * L, L) == 0) {
+                    seen = true;
+                    break;
+                }
+                s = (s + 1) & (cap - 1);
+            }
+            if (!seen) {
+                slots[s] = (uint32_t)i;
+                first[i] = 1;
+            }
         }
-        for (; i < L_; i++) h = (h ^ p[i]) * 0x100000001b3ull;
-        return h ^ (h >> 29);
-    }
-    bool put(uint32_t idx) {
-        const uint8_t *row = rows_ + (size_t)idx * L_;
-        size_t s = hash(row) & (slots_.size() - 1);
-        while (slots_[s] != UINT32_MAX) {
-            if (memcmp(rows_ + (size_t)slots_[s] * L_, row, L_) == 0) return false;
-            s = (s + 1) & (slots_.size() - 1);
-        }
-        slots_[s] = idx;
-        count_++;
-        return true;
-    }
-    void grow() {
-        std::vector<uint32_t> old;
-        old.swap(slots_);
-        slots_.assign(old.size() * 2, UINT32_MAX);
-        count_ = 0;
-        for (uint32_t v : old)
-            if (v != UINT32_MAX) put(v);
-    }
-    const uint8_t *rows_;
-    uint32_t L_;
-    std::vector<uint32_t> slots_;
-    size_t count_ = 0;
-};
+    });
+    uniq.clear();
+    for (uint64_t i = 0; i < n; i++)
+        if (first[i]) uniq.push_back((uint32_t)i);
+}
 
 }  // namespace
 
@@ -360,20 +374,19 @@ static int cluster_run(const char *input_fasta, uint32_t max_divergence, int out
         pending_msg = recs.err_msg;
     }
 
+    const double t_loaded = now_seconds();
     if (n > 0) {
         const uint32_t Lw = (uint32_t)L;
         // exact-duplicate skip (src/cluster.rs:46-48): first occurrences only, input order
         std::vector<uint32_t> uniq;
         uniq.reserve(n);
-        {
-            RowSet seen(codes.data(), Lw);
-            for (uint64_t i = 0; i < n; i++)
-                if (seen.insert((uint32_t)i)) uniq.push_back((uint32_t)i);
-        }
+        first_occurrences(codes.data(), n, Lw, uniq);
+        log_line(2, "parsed %llu records in %.2f s, %zu distinct found in %.2f s", (unsigned long long)n,
+                 t_loaded - t_start, uniq.size(), now_seconds() - t_loaded);
         std::vector<uint32_t> centroid_of(n, UINT32_MAX);  // record -> centroid ordinal
         std::vector<uint32_t> centroid_rec;                // centroid ordinal -> record
 
-        DbGuard centroids;
+        DbGuard centroids, cand;
         rc = smafa_db_create(&centroids.db, device, alphabet, Lw);
         if (rc) return rc;
 
@@ -383,7 +396,6 @@ static int cluster_run(const char *input_fasta, uint32_t max_divergence, int out
         std::vector<uint32_t> cand_centroid;   // candidate ordinal -> centroid ordinal it became (or NONE)
         size_t pos = 0, B = 1024, n_batches = 0;
         double t_old = 0, t_cand = 0, t_seq = 0, t_append = 0;
-        log_line(2, "parsed %llu records (%zu distinct) in %.2f s", (unsigned long long)n, uniq.size(), now_seconds() - t_start);
         while (pos < uniq.size()) {
             n_batches++;
             double t0 = now_seconds();
@@ -436,8 +448,11 @@ static int cluster_run(const char *input_fasta, uint32_t max_divergence, int out
                 }
             cand_hits.clear();
             if (!cand_pos.empty()) {
-                DbGuard cand;
-                rc = smafa_db_create(&cand.db, device, alphabet, Lw);
+                if (!cand.db) {  // one handle for every batch: its device buffers are reused
+                    rc = smafa_db_create(&cand.db, device, alphabet, Lw);
+                    if (rc) return rc;
+                }
+                rc = db_clear(cand.db);
                 if (rc) return rc;
                 rc = smafa_db_append(cand.db, cand_codes.data(), cand_pos.size());
                 if (rc) return rc;
@@ -510,23 +525,44 @@ static int cluster_run(const char *input_fasta, uint32_t max_divergence, int out
 
         log_line(2, "%zu batches: scans vs old centroids %.2f s, candidate scans %.2f s, sequential pass %.2f s, "
                     "centroid appends %.2f s", n_batches, t_old, t_cand, t_seq, t_append);
-        // src/cluster.rs:79-84
-        std::string text;
-        text.reserve(1 << 20);
-        for (uint64_t i = 0; i < n && rank == 0; i++) {
-            if (centroid_of[i] == UINT32_MAX) continue;  // duplicate: no line
-            text.append((const char *)&raw[i * L], L);
-            text.push_back('\t');
-            append_decoded(text, alphabet, &codes[(size_t)centroid_rec[centroid_of[i]] * L], Lw);
-            text.push_back('\n');
-            if (text.size() > (1u << 20)) {
-                rc = write_all(out_fd, text.data(), text.size());
+        // src/cluster.rs:79-84.  Every line is "raw record \t centroid string \n" = 2L + 2 bytes, so line k of the
+        // output sits at byte k * (2L + 2): blocks of lines are formatted by all threads and written in order.
+        if (rank == 0) {
+            const double t_out = now_seconds();
+            std::vector<uint32_t> lines;  // records that print (duplicates do not), input order
+            lines.reserve(uniq.size());
+            for (uint64_t i = 0; i < n; i++)
+                if (centroid_of[i] != UINT32_MAX) lines.push_back((uint32_t)i);
+            char letters[32];
+            for (int c = 0; c < 32; c++) letters[c] = letter_of(alphabet, (uint8_t)c);
+            const size_t line_bytes = 2 * L + 2, block_lines = 1u << 20;
+            const unsigned T = lines.size() >= (1u << 16) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+            std::vector<char> text(std::min(block_lines, lines.size()) * line_bytes);
+            for (size_t k0 = 0; k0 < lines.size(); k0 += block_lines) {
+                const size_t nk = std::min(block_lines, lines.size() - k0);
+                auto fill = [&](unsigned t) {
+                    for (size_t k = nk * t / T, e = nk * (t + 1) / T; k < e; k++) {
+                        const uint32_t i = lines[k0 + k];
+                        char *o = &text[k * line_bytes];
+                        memcpy(o, &raw[(size_t)i * L], L);
+                        o[L] = '\t';
+                        const uint8_t *c = &codes[(size_t)centroid_rec[centroid_of[i]] * L];
+                        for (size_t j = 0; j < L; j++) o[L + 1 + j] = letters[c[j] & 31];
+                        o[2 * L + 1] = '\n';
+                    }
+                };
+                if (T == 1) {
+                    fill(0);
+                } else {
+                    std::vector<std::thread> pool;
+                    for (unsigned t = 0; t < T; t++) pool.emplace_back(fill, t);
+                    for (auto &th : pool) th.join();
+                }
+                rc = write_all(out_fd, text.data(), nk * line_bytes);
                 if (rc) return rc;
-                text.clear();
             }
+            log_line(2, "%zu lines written in %.2f s", lines.size(), now_seconds() - t_out);
         }
-        rc = write_all(out_fd, text.data(), text.size());
-        if (rc) return rc;
         log_line(1, "Clustering complete, took %llu seconds. Clustered %llu sequences into %zu clusters.",  // src/cluster.rs:87-92
                  (unsigned long long)(now_seconds() - t_start), (unsigned long long)n, centroid_rec.size());
     }
