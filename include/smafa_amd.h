@@ -106,7 +106,9 @@ void smafa_db_destroy(smafa_db *db); /* NULL-safe */
  * cluster's argmin with ties to the lowest index (src/cluster.rs:54-68: first row per query).
  * The device may emit rows above kth(query) (its threshold only ever tightens); those are
  * removed before this call returns.
- * cap = capacity of `out` in rows.  If more rows qualify: SMAFA_ERR_CAPACITY, *n_out = rows needed.
+ * cap = capacity of `out` in rows.  If more rows qualify: SMAFA_ERR_CAPACITY, *n_out = rows needed; the handle
+ * keeps those rows, and the same call repeated with a larger buffer (same query bytes and bounds, store
+ * unchanged) is answered from them without a second scan.  Any other call to smafa_scan_hits drops them.
  */
 int smafa_scan_hits(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div,
                     uint32_t max_num_hits, smafa_hit *out, uint64_t cap, uint64_t *n_out);

@@ -165,6 +165,47 @@ def test_capacity_error_reports_rows_needed():
     store.close()
 
 
+def test_grow_and_retry_is_never_stale():
+    """after SMAFA_ERR_CAPACITY the handle keeps the rows for the identical retry only: other queries, other
+    bounds or a changed store are scanned afresh"""
+    rng = np.random.default_rng(17)
+    s, q = planted(rng, 3000, 40, 4, 30, 5)
+    store = smafa_amd.SubjectStore(40, 0)
+    store.push(s)
+    l = _lib.lib()
+
+    def call(queries, div, cap):
+        out = np.zeros(max(cap, 1), dtype=smafa_amd.HIT_DTYPE)
+        n_out = C.c_uint64(0)
+        rc = l.smafa_scan_hits(store._h, queries.ctypes.data, len(queries), div, _lib.NONE, out.ctypes.data, cap, C.byref(n_out))
+        return rc, n_out.value, out[: min(n_out.value, cap)]
+
+    want = oracle.scan_codes(s, q, 12)
+    assert len(want) >= 30
+    rc, need, _ = call(q, 12, 3)
+    assert rc == _lib.ERR_CAPACITY and need == len(want)
+    rc, n, rows = call(q, 12, need)                      # the retry: same request, served from the kept rows
+    assert rc == 0 and rows.tobytes() == want.tobytes()
+    rc, n, rows = call(q, 12, need)                      # and once more: kept rows are gone, scanned afresh
+    assert rc == 0 and rows.tobytes() == want.tobytes()
+    # a different batch of the same shape after an overflow must not see the kept rows
+    q2 = q[::-1].copy()
+    assert call(q, 12, 3)[0] == _lib.ERR_CAPACITY
+    rc, n, rows = call(q2, 12, 1 << 16)
+    assert rc == 0 and rows.tobytes() == oracle.scan_codes(s, q2, 12).tobytes()
+    # other bound
+    assert call(q, 12, 3)[0] == _lib.ERR_CAPACITY
+    rc, n, rows = call(q, 11, 1 << 16)
+    assert rc == 0 and rows.tobytes() == oracle.scan_codes(s, q, 11).tobytes()
+    # store changed between the overflow and the retry
+    assert call(q, 12, 3)[0] == _lib.ERR_CAPACITY
+    store.push(q[:4])
+    s2 = np.concatenate([s, q[:4]])
+    rc, n, rows = call(q, 12, 1 << 16)
+    assert rc == 0 and rows.tobytes() == oracle.scan_codes(s2, q, 12).tobytes()
+    store.close()
+
+
 def test_dense_hits_overflow_path():
     """every pair qualifies: more rows than the device scratch holds -> query range is split"""
     rng = np.random.default_rng(8)
