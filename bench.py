@@ -42,6 +42,8 @@ def main() -> None:
     ap.add_argument("--seq-len", type=int, default=60)
     ap.add_argument("--alphabet", choices=["aa", "nt"], default="aa")
     ap.add_argument("--max-div", type=int, default=5)
+    ap.add_argument("--n-frac", type=float, default=0.0,
+                    help="nt only: each column becomes N with this probability (SURVEY 8d variant B: 0.001, 3-plane store)")
     ap.add_argument("--query-block", type=int, default=0, help="queries per workgroup pass (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream", action="store_true", help="skip the one-query-per-pass leg (clean rocprof stats)")
@@ -80,7 +82,7 @@ def main() -> None:
 
     # ---- synthetic workload: identical DB on every rank, disjoint query shards
     t_gen = time.time()
-    subj = synth.subjects(N, L, alphabet, seed=1)
+    subj = synth.subjects(N, L, alphabet, seed=1 if alphabet else 2, n_frac=args.n_frac)  # seeds of SURVEY 8d
     all_q, planted_row, planted_subs = synth.queries(subj, Q * world, alphabet, seed=3, max_subs=max_subs)
     q_lo = rank * Q
     my_q = all_q[q_lo:q_lo + Q]
@@ -278,9 +280,10 @@ def main() -> None:
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": "%d x %d %s subject store (uniform letters, 1%% duplicate rows, seed 1) replicated per GPU; "
+                "workload": "%d x %d %s subject store (uniform letters, 1%% duplicate rows, seed %d%s) replicated per GPU; "
                             "%d planted queries per GPU per step (0..%d substitutions, seed 3); max-divergence %d"
-                            % (N, L, args.alphabet, Q, max_subs, D),
+                            % (N, L, args.alphabet, 1 if alphabet else 2,
+                               ", N with probability %g per column" % args.n_frac if args.n_frac else "", Q, max_subs, D),
                 "db_rows": N, "seq_len": L, "alphabet": args.alphabet, "queries_per_gpu": Q, "max_divergence": D,
                 "parallelism": "query shards x%d, DB replicated, RCCL all_gather of row lists" % world,
             },
