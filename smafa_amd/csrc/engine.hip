@@ -73,6 +73,7 @@ struct smafa_db {
     bool use_filter = true;  // exact lower-bound prefilter in the scan kernel (SMAFA_FILTER=0 disables)
     uint32_t tiles_override = 0;  // SMAFA_TILES
     bool lazy = true;             // filter-plane-resident kernel where it applies (SMAFA_LAZY=0 disables)
+    uint32_t wide_from = 3;       // words per plane from which scan_wide_kernel replaces the per-length kernels (SMAFA_WIDE_FROM)
     // what the last launch used (smafa_last_scan_plan)
     uint32_t plan_lazy = 0, plan_tiles = 1, plan_qblocks = 1;
     int n_cu = 256;
@@ -219,22 +220,43 @@ static void launch_scan_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
 // without --max-divergence (bound = L) and short sequences with a loose bound keep the all-planes kernel.
 static bool use_lazy(const smafa_db *db, uint32_t thr0) {
     const uint32_t cols = std::min<uint32_t>(32u, db->L);
-    return db->lazy && db->use_filter && db->W <= 4 && thr0 * 4u < cols;
+    return db->lazy && db->use_filter && db->W <= 2 && thr0 * 4u < cols;
+}
+
+// More than two words per plane (L > 64): scan_wide_kernel under the same rule — its levels 1 and 2 are the lazy
+// kernel's, with 16 subjects per lane whatever the length (measured 5-27 % faster than per-length instantiations
+// that keep every filter word resident, profiles/r01_length_probe.txt).  When the bound is too loose for the
+// prefilter, or it is switched off: scan_kernel (W <= 4) / scan_generic_kernel.  SMAFA_WIDE_FROM=n (>= 3) moves
+// the switch to n words.
+static bool use_wide(const smafa_db *db, uint32_t thr0) {
+    return db->lazy && db->use_filter && db->W >= db->wide_from && thr0 * 4u < 32u && wide_fits((int)db->PQ, (int)db->W);
 }
 
 static uint32_t tiles_per_wave(const smafa_db *db, bool lazy) {
-    if (lazy) {
-        if (db->W >= 3) return 2u;  // the prefilter plane is 3-4 words per subject: 8 subjects per lane
-        return (db->W == 2 && db->tiles_override == 8) ? 8u : 4u;
-    }
+    if (lazy) return 4u;  // W <= 2: 16 subjects per lane
     if (db->W > 2) return 1;
     if (db->tiles_override == 4) return db->P == 2 ? 4u : 2u;
     if (db->tiles_override == 1 || db->tiles_override == 2) return db->tiles_override;
     return 2u;
 }
 
+template <int PS, int PQ>
+static void launch_wide_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
+    if (a.hits == nullptr && a.k_tight == 1)
+        hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, true>), dim3(grid), dim3(256), 0, db->stream,
+                           reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a, db->W);
+    else
+        hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, false>), dim3(grid), dim3(256), 0, db->stream,
+                           reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a, db->W);
+}
+
 static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid, uint32_t T,
                         bool lazy) {
+    if (lazy && db->W >= db->wide_from) {  // any length above 64 columns
+        if (db->P == 2) return launch_wide_t<2, 3>(db, d_qrec, a, grid);
+        if (db->P == 3) return launch_wide_t<3, 3>(db, d_qrec, a, grid);
+        return launch_wide_t<5, 5>(db, d_qrec, a, grid);
+    }
     if (lazy) {  // filter-plane-resident kernel
 #define SMAFA_LAZY(PS_, PQ_, W_, T_)                                  \
     if (db->P == PS_ && db->PQ == PQ_ && db->W == W_ && T == T_) {    \
@@ -242,10 +264,7 @@ static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanAr
         return;                                                       \
     }
         SMAFA_LAZY(2, 3, 2, 4) SMAFA_LAZY(3, 3, 2, 4) SMAFA_LAZY(5, 5, 2, 4)
-        SMAFA_LAZY(2, 3, 2, 8) SMAFA_LAZY(3, 3, 2, 8) SMAFA_LAZY(5, 5, 2, 8)
         SMAFA_LAZY(2, 3, 1, 4) SMAFA_LAZY(3, 3, 1, 4) SMAFA_LAZY(5, 5, 1, 4)
-        SMAFA_LAZY(2, 3, 3, 2) SMAFA_LAZY(3, 3, 3, 2) SMAFA_LAZY(5, 5, 3, 2)
-        SMAFA_LAZY(2, 3, 4, 2) SMAFA_LAZY(3, 3, 4, 2) SMAFA_LAZY(5, 5, 4, 2)
 #undef SMAFA_LAZY
     }
 #define SMAFA_CASE(PS_, PQ_, W_, T_)                          \
@@ -282,9 +301,10 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
                         uint32_t tile_end, uint32_t k_tight, uint32_t thr0, smafa_hit *d_shards, uint64_t shard_cap,
                         unsigned long long *d_shard_counts) {
     ScanArgs a;
-    const bool specialised = db->W <= 4;  // else scan_generic_kernel
-    const bool lazy = specialised && use_lazy(db, thr0);
-    const uint32_t T = specialised ? tiles_per_wave(db, lazy) : (uint32_t)kGenericTiles;
+    const bool specialised = db->W <= 4;  // else scan_wide_kernel / scan_generic_kernel
+    const bool wide = use_wide(db, thr0);
+    const bool lazy = wide || (specialised && use_lazy(db, thr0));
+    const uint32_t T = wide ? (uint32_t)kWideTiles : specialised ? tiles_per_wave(db, lazy) : (uint32_t)kGenericTiles;
     a.tile_begin = tile_begin;
     a.tile_end = tile_end;
     a.n_wg_tiles = (tile_end - tile_begin + kWgWaves * T - 1) / (kWgWaves * T);
@@ -565,9 +585,10 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     if (const char *fv = getenv("SMAFA_FILTER")) db->use_filter = atoi(fv) != 0;
     if (const char *tv = getenv("SMAFA_TILES")) {
         const int t = atoi(tv);
-        db->tiles_override = (t == 1 || t == 2 || t == 4 || t == 8) ? (uint32_t)t : 0u;
+        db->tiles_override = (t == 1 || t == 2 || t == 4) ? (uint32_t)t : 0u;
     }
     if (const char *lv = getenv("SMAFA_LAZY")) db->lazy = atoi(lv) != 0;
+    if (const char *wv = getenv("SMAFA_WIDE_FROM")) db->wide_from = (uint32_t)std::max(3, atoi(wv));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) db->n_cu = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&db->own_stream, hipStreamNonBlocking);

@@ -21,7 +21,8 @@
 // prefilter's plane, the rest on demand: scan_lazy_kernel).
 //
 // Query records (u32 words, stride qrec_stride(P, W)):
-//     [ filter-plane words 0..W-1 | bound slot | the other planes' words ]
+//     [ filter word 0 | filter word 1 | bound slot | filter words 2..W-1 | the other planes' words ]
+// (one-word records: [ filter word 0 | bound slot | ... ]) — see qslot() / bound_slot().
 // The 4 waves of a workgroup walk the same query block, so they stage 64 records at a time in LDS
 // (double-buffered, one barrier per 64 queries) and every wave broadcast-reads a record into VGPRs with
 // ds_read_b128 (all lanes read one address: conflict-free).  Why not scalar registers: measured on
@@ -65,10 +66,13 @@ __host__ __device__ constexpr int qrec_stride(int planes, int words) { return ro
 // {G,T}, so it sees both transitions (A<->G, C<->T), the commonest real substitutions; bit 0 would miss them.
 __host__ __device__ constexpr int filter_plane(int planes) { return planes == 3 ? 1 : 0; }
 // slot of word w of plane p inside a record
+// The bound sits right after the first two filter words, so the first uint4 of a record holds everything
+// levels 1 and 2 of scan_wide_kernel need: [f0 f1 bound f2 f3 ... | other planes] ([f0 bound] for one word).
+__host__ __device__ constexpr int bound_slot(int words) { return words < 2 ? words : 2; }
 __host__ __device__ constexpr int qslot(int planes, int words, int p, int w) {
-    return p == filter_plane(planes) ? w : words + 1 + (p < filter_plane(planes) ? p : p - 1) * words + w;
+    return p == filter_plane(planes) ? (w < bound_slot(words) ? w : w + 1)
+                                     : words + 1 + (p < filter_plane(planes) ? p : p - 1) * words + w;
 }
-__host__ __device__ constexpr int bound_slot(int words) { return words; }
 
 struct ScanArgs {
     uint32_t tile_begin, tile_end;  // wave-tile range of this launch
@@ -332,10 +336,10 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
                             uint32_t m2 = s[t][FP * W].z ^ qw[0], m3 = s[t][FP * W].w ^ qw[0];
 #pragma unroll
                             for (int w = 1; w < W; w++) {
-                                m0 = or_xor(m0, s[t][FP * W + w].x, qw[w]);
-                                m1 = or_xor(m1, s[t][FP * W + w].y, qw[w]);
-                                m2 = or_xor(m2, s[t][FP * W + w].z, qw[w]);
-                                m3 = or_xor(m3, s[t][FP * W + w].w, qw[w]);
+                                m0 = or_xor(m0, s[t][FP * W + w].x, qw[qslot(PQ, W, FP, w)]);
+                                m1 = or_xor(m1, s[t][FP * W + w].y, qw[qslot(PQ, W, FP, w)]);
+                                m2 = or_xor(m2, s[t][FP * W + w].z, qw[qslot(PQ, W, FP, w)]);
+                                m3 = or_xor(m3, s[t][FP * W + w].w, qw[qslot(PQ, W, FP, w)]);
                             }
                             if (kPair) {
                                 // popcount(a & b) <= min(popcount a, popcount b): one popcount bounds two subjects
@@ -557,10 +561,10 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
                             uint32_t m2 = f[t][0].z ^ qw[0], m3 = f[t][0].w ^ qw[0];
 #pragma unroll
                             for (int w = 1; w < W; w++) {
-                                m0 = or_xor(m0, f[t][w].x, qw[w]);
-                                m1 = or_xor(m1, f[t][w].y, qw[w]);
-                                m2 = or_xor(m2, f[t][w].z, qw[w]);
-                                m3 = or_xor(m3, f[t][w].w, qw[w]);
+                                m0 = or_xor(m0, f[t][w].x, qw[qslot(PQ, W, FP, w)]);
+                                m1 = or_xor(m1, f[t][w].y, qw[qslot(PQ, W, FP, w)]);
+                                m2 = or_xor(m2, f[t][w].z, qw[qslot(PQ, W, FP, w)]);
+                                m3 = or_xor(m3, f[t][w].w, qw[qslot(PQ, W, FP, w)]);
                             }
                             tsign[t] = kPair ? ((__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu))
                                              : (or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
@@ -610,7 +614,208 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
     }
 }
 
-// Any (planes, words) shape — the fallback for lengths without a specialisation (L > 128).  A lane keeps word 0
+// ---------------------------------------------------------------------------------------------
+// L > 64 (more than 2 words per plane): the same three levels with the register footprint of a 64-column
+// store, for any length.  A lane keeps words 0 and 1 of the filter plane of its 16 subjects (4 wave tiles);
+// level 1 bounds word 0, level 2 the two-word fold (two subjects per popcount) — both exact lower bounds on the
+// distance, as in scan_lazy_kernel.  The full comparison (level 3, rare while the bound is small) streams the
+// surviving tile's planes from L2/HBM word by word and reads the query's words from LDS, so its registers do not
+// grow with W; it stops as soon as every subject of the wave is past the bound.  W is a runtime argument: one
+// instantiation per plane pair serves every length.  A chunk holds as many query records as fit 768 LDS vectors;
+// the first vector of each record ([f0 f1 bound ..]) is staged a second time in a dense array, so the hot loop
+// reads LDS at a compile-time stride whatever W is.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWideTiles = 4;
+constexpr int kWideStage = 768;  // uint4 per LDS buffer
+__host__ __device__ constexpr bool wide_fits(int planes, int words) { return qrec_stride(planes, words) / 4 <= kWideStage; }
+
+template <int PS, int PQ, bool SEED>
+__global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restrict__ planes,
+                                                           const uint32_t *__restrict__ qrec, ScanArgs a, uint32_t W) {
+    constexpr int T = kWideTiles;
+    constexpr int NV = kWideStage / 256;
+    constexpr int FP = filter_plane(PQ);
+    static_assert(FP < PS && PS <= PQ, "the filter plane must be one the subjects store");
+    const uint32_t RS = (uint32_t)qrec_stride(PQ, (int)W);
+    const uint32_t RV = RS / 4;
+    const uint32_t BS = (uint32_t)bound_slot((int)W);
+    const uint32_t chunk = min((uint32_t)kChunk, (uint32_t)kWideStage / RV);  // >= 1: the host checks wide_fits()
+    __shared__ uint4 stage[2][kWideStage];
+    __shared__ uint4 heads[2][kChunk];  // first vector of every staged record, at a compile-time stride
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t wg_tile = blockIdx.x % a.n_wg_tiles;
+    const uint32_t qblock = blockIdx.x / a.n_wg_tiles;
+    const uint32_t tile0 = a.tile_begin + (wg_tile * kWgWaves + wave) * T;
+    const bool active = tile0 < a.tile_end;
+    const size_t tile_stride = (size_t)PS * W * 64;
+
+    uint4 f[T][2];  // filter-plane words 0 and 1; tile slots past the range copy tile_begin (valid memory)
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        const bool live = tile0 + t < a.tile_end;
+        const uint4 *src = planes + (size_t)(live ? tile0 + t : a.tile_begin) * tile_stride + (size_t)FP * W * 64 + lane;
+        f[t][0] = src[0];
+        f[t][1] = src[64];
+    }
+    const uint32_t q0 = a.q_begin + qblock * a.qb_size;
+    const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
+
+    uint4 pre[NV];
+    auto fetch = [&](uint32_t qc) {
+        const uint32_t nqc = min(chunk, q1 - qc);
+        const uint4 *src = reinterpret_cast<const uint4 *>(qrec + (size_t)qc * RS);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const uint32_t idx = tid + v * 256;
+            if (idx < nqc * RV) {
+                uint4 x = src[idx];
+                if (idx % RV == BS / 4) {
+                    const uint32_t nu = ~(a.thr ? ld_relaxed(a.thr + qc + idx / RV) : a.thr0);
+                    const uint32_t c = BS & 3u;
+                    x.x = c == 0 ? nu : x.x;
+                    x.y = c == 1 ? nu : x.y;
+                    x.z = c == 2 ? nu : x.z;
+                    x.w = c == 3 ? nu : x.w;
+                }
+                pre[v] = x;
+            }
+        }
+    };
+    auto commit = [&](int buf, uint32_t qc) {
+        const uint32_t nqc = min(chunk, q1 - qc);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const uint32_t idx = tid + v * 256;
+            if (idx < nqc * RV) {
+                stage[buf][idx] = pre[v];
+                if (idx % RV == 0) heads[buf][idx / RV] = pre[v];
+            }
+        }
+    };
+    // full comparison of the query record at `rec` (LDS) against the 4 subjects this lane owns in `tile`
+    auto wide_compare = [&](uint32_t tile, const uint32_t *rec, uint32_t q) {
+        const uint32_t U = ~rec[BS];
+        const uint4 *src = planes + (size_t)tile * tile_stride + lane;
+        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        for (uint32_t w = 0; w < W; w++) {
+            uint32_t extra = 0;
+#pragma unroll
+            for (int p = PS; p < PQ; p++) extra |= rec[qslot(PQ, (int)W, p, (int)w)];
+            uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
+#pragma unroll
+            for (int p = 0; p < PS; p++) {
+                const uint4 v = src[((size_t)p * W + w) * 64];
+                const uint32_t qv = rec[qslot(PQ, (int)W, p, (int)w)];
+                m0 = or_xor(m0, v.x, qv);
+                m1 = or_xor(m1, v.y, qv);
+                m2 = or_xor(m2, v.z, qv);
+                m3 = or_xor(m3, v.w, qv);
+            }
+            d0 += __builtin_popcount(m0);
+            d1 += __builtin_popcount(m1);
+            d2 += __builtin_popcount(m2);
+            d3 += __builtin_popcount(m3);
+            // distances only grow: once all 256 subjects of the wave are past the bound nothing can come out
+            // (two-word steps with both loads in flight were measured: more registers, slower level 1)
+            if (__ballot(min(min(d0, d1), min(d2, d3)) <= U) == 0ull) return;
+        }
+        const uint32_t subj0 = tile * kWaveTile + lane * 4u;
+        const uint32_t d[4] = {d0, d1, d2, d3};
+        if (SEED) {
+            uint32_t lo = 0xffffffffu;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (subj0 + k < a.n_subjects) lo = min(lo, d[k]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+            if (lane == 0 && lo < U) atomicMin(a.thr + q, lo);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, q, subj0 + k, d[k]);
+        }
+    };
+
+    if (q0 < q1) {
+        fetch(q0);
+        commit(0, q0);
+    }
+    __syncthreads();
+    int buf = 0;
+    bool filter_on = a.use_filter != 0;
+    bool level1_on = true;
+    uint32_t chunk_no = 0;
+    for (uint32_t qc = q0; qc < q1; qc += chunk, buf ^= 1, chunk_no++) {
+        const uint32_t nqc = min(chunk, q1 - qc);
+        const bool more = qc + chunk < q1;
+        if (more) fetch(qc + chunk);
+        if (active) {
+            // pinned to scalars: hipcc cannot see through __ballot that these flags are wave-uniform
+            const bool probe =
+                __builtin_amdgcn_readfirstlane((int)(a.use_filter && (filter_on || (chunk_no & 15u) == 0))) != 0;
+            const uint32_t *rec = reinterpret_cast<const uint32_t *>(&stage[buf][0]);
+            uint32_t passes = 0, level1_passes = 0;
+            const bool l1 = __builtin_amdgcn_readfirstlane((int)level1_on) != 0;
+            for (uint32_t i = 0; i < nqc; i++, rec += RS) {
+                uint32_t live = (1u << T) - 1u;  // dense neighbourhoods (no probe): every tile, exact comparison
+                if (probe) {
+                    const uint4 head = heads[buf][i];  // [f0 f1 bound ..]: one LDS read at a constant stride
+                    const uint32_t qw0 = head.x, qw1 = head.y, nu = head.z;
+                    if (l1) {  // level 1: word 0 of the filter plane
+                        uint32_t any1 = 0;
+#pragma unroll
+                        for (int t = 0; t < T; t++) {
+                            const uint32_t u0 = __builtin_popcount(f[t][0].x ^ qw0) + nu;
+                            const uint32_t u1 = __builtin_popcount(f[t][0].y ^ qw0) + nu;
+                            const uint32_t u2 = __builtin_popcount(f[t][0].z ^ qw0) + nu;
+                            const uint32_t u3 = __builtin_popcount(f[t][0].w ^ qw0) + nu;
+                            any1 = t ? or3(or3(u0, u1, u2), u3, any1) : (or3(u0, u1, u2) | u3);
+                        }
+                        const bool go = __ballot((int32_t)any1 < 0) != 0ull;
+                        level1_passes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(level1_passes + (go ? 1u : 0u)));
+                        if (!go) continue;
+                    }
+                    // level 2: words 0 and 1 folded, two subjects per popcount
+                    live = 0;
+#pragma unroll
+                    for (int t = 0; t < T; t++) {
+                        const uint32_t m0 = or_xor(f[t][0].x ^ qw0, f[t][1].x, qw1);
+                        const uint32_t m1 = or_xor(f[t][0].y ^ qw0, f[t][1].y, qw1);
+                        const uint32_t m2 = or_xor(f[t][0].z ^ qw0, f[t][1].z, qw1);
+                        const uint32_t m3 = or_xor(f[t][0].w ^ qw0, f[t][1].w, qw1);
+                        const uint32_t sign =
+                            SMAFA_AND_PAIR ? ((__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu))
+                                           : (or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
+                                                  __builtin_popcount(m2) + nu) |
+                                              (__builtin_popcount(m3) + nu));
+                        if (__ballot((int32_t)sign < 0) != 0ull) live |= 1u << t;
+                    }
+                    live = (uint32_t)__builtin_amdgcn_readfirstlane((int)live);
+                    if (live == 0) continue;
+                    passes++;
+                }
+                while (live) {  // level 3: exact, tile by tile — ONE copy of the comparison code
+                    const uint32_t t = (uint32_t)__builtin_ctz(live);
+                    live &= live - 1;
+                    if (tile0 + t < a.tile_end) wide_compare(tile0 + t, rec, qc + i);
+                }
+            }
+            if (probe) {
+                passes = (uint32_t)__builtin_amdgcn_readfirstlane((int)passes);
+                filter_on = passes * 4u <= nqc;
+                level1_on = l1 ? level1_passes * 2u <= nqc : (chunk_no & 15u) == 15u;
+            }
+        }
+        if (more) commit(buf ^ 1, qc + chunk);
+        __syncthreads();
+    }
+}
+
+// Any (planes, words) shape — the fallback for L > 128 when the bound is too loose for scan_wide_kernel's
+// prefilter to prune (or the prefilter is switched off).  A lane keeps word 0
 // of the prefilter plane of its 16 subjects (4 wave tiles) in registers and applies the level-1 bound of the
 // specialised kernels (exact: popcount over the first 32 columns of one plane <= distance); only for queries
 // that survive it are the subjects' words re-read from L2/HBM, plane by plane, for the full comparison.

@@ -70,6 +70,36 @@ def test_scan_hits_equals_oracle(alphabet, n_letters, L):
         store.close()
 
 
+@pytest.mark.parametrize("alphabet,n_letters", [(0, 4), (0, 5), (1, 28)])
+@pytest.mark.parametrize("L", [65, 96, 128, 129, 160, 161, 257, 700])
+def test_wide_lengths_all_modes_equal_oracle(alphabet, n_letters, L):
+    """more than 64 columns: scan_wide_kernel while the bound prunes (small D), scan_kernel (up to 128 columns) or
+    scan_generic_kernel beyond;
+    fixed bounds, best hit and k-th bounds, clustered neighbourhoods (levels 2 and 3 are exercised)"""
+    rng = np.random.default_rng(77 * L + n_letters)
+    n = 5000
+    s, q = planted(rng, n, L, n_letters, 90, 9)
+    s[1000:1400] = s[3]                       # a dense neighbourhood: 400 copies ...
+    for r in s[1000:1400]:
+        for _ in range(rng.integers(0, 5)):   # ... each 0-4 substitutions away
+            r[rng.integers(0, L)] = rng.integers(0, min(n_letters, 4))
+    q[:10] = s[3]
+    store = smafa_amd.SubjectStore(L, alphabet)
+    store.push(s)
+    for D in (0, 2, 7, 8, 40, L):
+        got = store.scan(q, max_divergence=D)
+        assert got.tobytes() == oracle.scan_codes(s, q, D).tobytes(), (L, D)
+        plan = store.last_scan_plan()
+        assert plan["filter_plane_resident"] == (D < 8) and plan["tiles_per_wave"] == (4 if D < 8 or L > 128 else 1)
+    for D, k in ((6, 1), (None, 1), (5, 3), (None, 4), (7, 450)):
+        got = store.scan(q, max_divergence=D, max_num_hits=k)
+        want = expected_with_k(oracle.scan_codes(s, q, L if D is None else D), k)
+        assert got.tobytes() == want.tobytes(), (L, D, k)
+    store.set_prefilter(False)
+    assert store.scan(q, max_divergence=3).tobytes() == oracle.scan_codes(s, q, 3).tobytes()
+    store.close()
+
+
 def test_nt_scan_equals_reference_arithmetic():
     """NT path vs the reference's own arithmetic (5-bit one-hot, xor + popcount / 2) on ASCII input"""
     rng = np.random.default_rng(2)
