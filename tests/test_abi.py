@@ -250,3 +250,33 @@ def test_cluster_sharded_argument_checks(tmp_path):
     calls = []
     cb = _lib.ALLGATHER_FN(lambda *a: calls.append(a) or 1)
     assert l.smafa_cluster_sharded(os.fsencode(empty), 3, 1, 0, 0, 1, 2, cb, None) == -5 and not calls
+
+
+def test_dbfile_property_any_shape(tmp_path):
+    """hypothesis over shapes and letters: makedb bytes == the oracle's makedb bytes, and read -> write is the
+    identity on the file (the v2 wire format of src/lib.rs:54-60,161-162 for every window count and varint width)"""
+    from hypothesis import given, settings, strategies as st
+
+    valid = b"ACGTUNRYKMSWBDHVacgtunrykmswbdhv-"
+    counter = [0]
+
+    @settings(max_examples=30, deadline=None)
+    @given(st.integers(1, 140), st.integers(1, 40), st.integers(0, 2**32 - 1))
+    def check(L, n, seed):
+        counter[0] += 1
+        rng = np.random.default_rng(seed)
+        letters = np.frombuffer(valid, dtype=np.uint8)
+        # skew towards one letter now and then: long runs of equal windows, small and large varints
+        p = rng.dirichlet(np.ones(len(letters)) * (0.05 if seed % 3 == 0 else 1.0))
+        rows = letters[rng.choice(len(letters), size=(n, L), p=p)]
+        f, a, b, c = (str(tmp_path / ("%s%d" % (x, counter[0]))) for x in "fabc")
+        oracle.write_fasta(f, [bytes(r) for r in rows])
+        smafa_amd.makedb(f, a)
+        assert oracle.run_cli("makedb", "-i", f, "-d", b).returncode == 0
+        assert open(a, "rb").read() == open(b, "rb").read()
+        alphabet, codes = smafa_amd.read_db(a)
+        assert alphabet == 0 and (codes == oracle.codes_from_ascii(rows, 0)).all()
+        smafa_amd.write_db(c, codes, 0)
+        assert open(c, "rb").read() == open(a, "rb").read()
+
+    check()
