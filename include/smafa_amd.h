@@ -124,7 +124,8 @@ void smafa_qset_destroy(smafa_qset *qs);
  * Asynchronous scan of a resident query set against the resident store on the handle's stream.
  * d_hits: device buffer of cap smafa_hit rows (unordered on return); d_count: device uint64 that
  * receives the number of qualifying rows (may exceed cap; only the first cap are stored).
- * max_div / max_num_hits as in smafa_scan_hits, except that rows above kth(query) are NOT removed.
+ * max_div / max_num_hits as in smafa_scan_hits, except that rows above kth(query) may remain: rows are kept
+ * when dist <= the device's final bound of their query, which is exact for k = 1 and >= kth(query) for k >= 2.
  */
 int smafa_scan_launch(smafa_db *db, smafa_qset *qs, uint32_t max_div, uint32_t max_num_hits, void *d_hits,
                       uint64_t cap, void *d_count);

@@ -83,6 +83,8 @@ struct smafa_db {
     DevBuf shard_rows, shard_counts;  // where the scan kernels append (kShards segments) before compaction
     DevBuf keys_a, keys_b, sort_tmp;
     smafa_qset scratch_q;     // query set of smafa_scan_hits / smafa_distances
+    smafa_qset scratch_q2;    // the compacted batch of queries the near-hit probe did not finish
+    bool two_phase = true;    // near-hit probe before the tightening path (SMAFA_TWO_PHASE=0 disables)
     // rows of a smafa_scan_hits call that ended in SMAFA_ERR_CAPACITY, kept for the caller's "grow and retry":
     // the retry with the same arguments against the same store is answered without scanning again
     std::vector<smafa_hit> retry_rows;
@@ -351,7 +353,12 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     }
     // the kernels append into kShards segments of a scratch block (twice the caller's capacity, so that an uneven
     // spread over the segments does not look like an overflow); compact_rows_kernel gathers them at the end
-    const uint64_t shard_cap = (2 * cap + kShards - 1) / kShards + 256;
+    // Tightening modes append every pair that is within its query's bound at that moment — 50-100 rows per query
+    // when the bound starts loose — of which the gather keeps the ones within the final bound: the scratch block is
+    // sized for the appended volume, the caller's buffer only has to hold what is kept.
+    uint64_t scratch_rows = 2 * cap;
+    if (k_tight) scratch_rows = std::max<uint64_t>(scratch_rows, std::min<uint64_t>((uint64_t)nq * 128u, 1ull << 27));
+    const uint64_t shard_cap = (scratch_rows + kShards - 1) / kShards + 256;
     int src = db->shard_rows.ensure(shard_cap * kShards * sizeof(smafa_hit));
     if (!src) src = db->shard_counts.ensure(kShards * sizeof(unsigned long long));
     if (src) return src;
@@ -394,8 +401,10 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     if (rc) return rc;
     HIP_TRY(hipEventRecord(db->ev1, db->stream));  // smafa_last_scan_ms: the scan kernels, not the gather below
     db->timed = true;
+    const uint32_t *final_thr = k_tight ? qs->thr.as<uint32_t>() : nullptr;
+    if (final_thr) HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), db->stream));
     hipLaunchKernelGGL(compact_rows_kernel, dim3(kShards), dim3(256), 0, db->stream, d_shards, d_shard_counts,
-                       (unsigned long long)shard_cap, d_hits, (unsigned long long)cap, d_count);
+                       (unsigned long long)shard_cap, d_hits, (unsigned long long)cap, d_count, final_thr);
     HIP_TRY(hipGetLastError());
     return SMAFA_OK;
 }
@@ -456,6 +465,22 @@ static int sort_rows_on_device(smafa_db *db, uint64_t count, uint32_t q_begin, u
     return SMAFA_OK;
 }
 
+// Append db->hits[0..count) — rows of queries [q_begin, q_end) — to `out`, ordered by (query, dist, subject).
+static int fetch_rows(smafa_db *db, uint64_t count, uint32_t q_begin, uint32_t q_end, std::vector<smafa_hit> &out) {
+    if (count == 0) return SMAFA_OK;
+    bool sorted = false;
+    if (count >= 4096) {  // small lists are cheaper to order on the host
+        int rc = sort_rows_on_device(db, count, q_begin, q_end, &sorted);
+        if (rc) return rc;
+    }
+    const size_t old = out.size();
+    out.resize(old + count);
+    HIP_TRY(hipMemcpyAsync(out.data() + old, db->hits.p, count * sizeof(smafa_hit), hipMemcpyDeviceToHost, db->stream));
+    HIP_TRY(hipStreamSynchronize(db->stream));
+    if (!sorted) std::sort(out.begin() + old, out.end(), hit_less);  // each range ordered => `out` ordered
+    return SMAFA_OK;
+}
+
 // Collect all qualifying rows of queries [q_begin, q_end) into `out` (host).  First the plain bound when there
 // is one (rows within max_div are usually few); if they do not fit, tighten to the k-th smallest distance; if
 // that still does not fit, halve the query range.  Ranges are visited in ascending query order and each is
@@ -493,18 +518,7 @@ static int collect_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_
         if (rc) return rc;
         return collect_range(db, qs, q_begin, q_end, max_div, max_num_hits, out);
     }
-    if (count == 0) return SMAFA_OK;
-    bool sorted = false;
-    if (count >= 4096) {  // small lists are cheaper to order on the host
-        int rc = sort_rows_on_device(db, count, q_begin, q_end, &sorted);
-        if (rc) return rc;
-    }
-    const size_t old = out.size();
-    out.resize(old + count);
-    HIP_TRY(hipMemcpyAsync(out.data() + old, db->hits.p, count * sizeof(smafa_hit), hipMemcpyDeviceToHost, db->stream));
-    HIP_TRY(hipStreamSynchronize(db->stream));
-    if (!sorted) std::sort(out.begin() + old, out.end(), hit_less);  // each range ordered => `out` ordered
-    return SMAFA_OK;
+    return fetch_rows(db, count, q_begin, q_end, out);
 }
 
 // Rows past n in the last tile keep their old bits; every kernel tests subject < n_subjects before it reports or
@@ -530,8 +544,69 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
     if (rc) return rc;
     rc = qset_fill(&db->scratch_q, db, query_codes, n_queries);
     if (rc) return rc;
-    rc = collect_range(db, &db->scratch_q, 0, (uint32_t)n_queries, max_div, max_num_hits, out);
-    if (rc) return rc;
+    bool collected = false;
+    // k-th-distance modes whose bound is loose or absent (`smafa query` without --max-divergence): the scan would
+    // run the all-planes kernel until each query's running bound has tightened.  Most queries of real inputs have
+    // their k nearest subjects within a few mismatches, so first ask the cheap question — one fixed-bound launch
+    // at a bound the prefilter prunes well at (d0).  A query with at least k rows within d0 is finished:
+    // its k-th smallest distance is <= d0, so every row it may print is among them.  Only the other queries take
+    // the tightening path, as a compacted batch.  Exact either way; when no query is finished the probe costs one
+    // fast launch (~10 % of the slow path), when d0 already overflows the buffer it is abandoned.
+    const uint32_t k_mode = max_num_hits == SMAFA_NONE ? 0u : max_num_hits;
+    // d0: the prefilter's first level looks at min(32, L) columns of one plane; at a bound of a sixth of them it
+    // still rejects all but a few percent of the (wave, query) steps (measured: the launch costs the same at
+    // bound 5 as at bound 3 for L = 60, 2-3x more at bound 7)
+    const uint32_t d0 = (std::min<uint32_t>(32u, db->L) - 1u) / 6u;
+    if (k_mode >= 1 && std::min<uint32_t>(max_div, db->L) > d0 && db->use_filter && db->lazy && db->two_phase &&
+        n_queries >= 16) {
+        const uint32_t nq = (uint32_t)n_queries;
+        unsigned long long count = 0;
+        rc = scan_range(db, &db->scratch_q, 0, nq, d0, 0, db->hits.as<smafa_hit>(), db->hits_cap(),
+                        db->count.as<unsigned long long>());
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(&count, db->count.p, sizeof count, hipMemcpyDeviceToHost, db->stream));
+        HIP_TRY(hipStreamSynchronize(db->stream));
+        if (count > 0 && count <= db->hits_cap()) {
+            std::vector<smafa_hit> near;
+            rc = fetch_rows(db, count, 0, nq, near);
+            if (rc) return rc;
+            std::vector<uint32_t> have(nq, 0);
+            for (const smafa_hit &h : near) have[h.query]++;
+            std::vector<uint32_t> rest;  // queries that still need the full answer, ascending
+            for (uint32_t q = 0; q < nq; q++)
+                if (have[q] < k_mode) rest.push_back(q);
+            if (rest.size() < nq) {
+                std::vector<smafa_hit> far;
+                if (!rest.empty()) {
+                    std::vector<uint8_t> rest_codes(rest.size() * (size_t)db->L);
+                    for (size_t i = 0; i < rest.size(); i++)
+                        memcpy(&rest_codes[i * db->L], query_codes + (size_t)rest[i] * db->L, db->L);
+                    rc = qset_fill(&db->scratch_q2, db, rest_codes.data(), rest.size());
+                    if (rc) return rc;
+                    rc = collect_range(db, &db->scratch_q2, 0, (uint32_t)rest.size(), max_div, max_num_hits, far);
+                    if (rc) return rc;
+                    for (smafa_hit &h : far) h.query = rest[h.query];  // ascending map: order is kept
+                }
+                // both lists are ordered and cover disjoint queries
+                out.reserve(near.size() + far.size());
+                size_t a = 0, b = 0;
+                while (a < near.size() || b < far.size()) {
+                    if (a < near.size() && have[near[a].query] < k_mode) {  // superseded by the full answer
+                        a++;
+                        continue;
+                    }
+                    if (b == far.size() || (a < near.size() && near[a].query < far[b].query)) out.push_back(near[a++]);
+                    else out.push_back(far[b++]);
+                }
+                collected = true;
+                log_line(2, "near-hit probe at bound %u finished %u of %u queries", d0, nq - (uint32_t)rest.size(), nq);
+            }
+        }
+    }
+    if (!collected) {
+        rc = collect_range(db, &db->scratch_q, 0, (uint32_t)n_queries, max_div, max_num_hits, out);
+        if (rc) return rc;
+    }
     if (max_num_hits != SMAFA_NONE && max_num_hits >= 1) {
         // drop rows above the k-th smallest distance of their query (the device bound only tightens)
         size_t w = 0, i = 0;
@@ -588,6 +663,7 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
         db->tiles_override = (t == 1 || t == 2 || t == 4) ? (uint32_t)t : 0u;
     }
     if (const char *lv = getenv("SMAFA_LAZY")) db->lazy = atoi(lv) != 0;
+    if (const char *pv2 = getenv("SMAFA_TWO_PHASE")) db->two_phase = atoi(pv2) != 0;
     if (const char *wv = getenv("SMAFA_WIDE_FROM")) db->wide_from = (uint32_t)std::max(3, atoi(wv));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) db->n_cu = prop.multiProcessorCount;
@@ -650,7 +726,7 @@ void smafa_db_destroy(smafa_db *db) {
     (void)hipSetDevice(db->device);
     if (db->d_planes) (void)hipFree(db->d_planes);
     for (DevBuf *b : {&db->upload, &db->hits, &db->count, &db->shard_rows, &db->shard_counts, &db->keys_a, &db->keys_b, &db->sort_tmp, &db->scratch_q.qrec,
-                      &db->scratch_q.thr, &db->scratch_q.cnt})
+                      &db->scratch_q.thr, &db->scratch_q.cnt, &db->scratch_q2.qrec, &db->scratch_q2.thr, &db->scratch_q2.cnt})
         b->release();
     if (db->ev0) (void)hipEventDestroy(db->ev0);
     if (db->ev1) (void)hipEventDestroy(db->ev1);

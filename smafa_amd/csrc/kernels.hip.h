@@ -988,9 +988,14 @@ __global__ void replane_kernel(const uint32_t *src, uint32_t *dst, uint64_t n_ti
 // After a scan: gather the kShards row segments into one contiguous list of at most `cap` rows and publish one
 // count.  If any segment overflowed its shard_cap (rows were dropped) the published count is forced above `cap`,
 // which is the "did not fit, retry" signal of the scan API.  One workgroup per segment.
+// thr != NULL (tightening modes): the scan appended every pair that was within the bound of its query AT THAT
+// TIME; only rows within the FINAL bound can be printed, so the gather keeps `dist <= thr[query]` and drops the
+// rest — typically 50-100 appended rows per query shrink to one or two before anything is sorted or crosses PCIe.
+// Kept rows land in arbitrary order through one wave-aggregated atomic per wave (*out_count zeroed by the host).
 __global__ __launch_bounds__(256) void compact_rows_kernel(const smafa_hit *shards, const unsigned long long *counts,
                                                            unsigned long long shard_cap, smafa_hit *out,
-                                                           unsigned long long cap, unsigned long long *out_count) {
+                                                           unsigned long long cap, unsigned long long *out_count,
+                                                           const uint32_t *thr) {
     const uint32_t s = blockIdx.x;
     unsigned long long before = 0, total = 0;
     bool dropped = false;
@@ -1002,9 +1007,34 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const smafa_hit *shar
     }
     const unsigned long long mine = counts[s] < shard_cap ? counts[s] : shard_cap;
     const smafa_hit *src = shards + (size_t)s * shard_cap;
-    for (unsigned long long i = threadIdx.x; i < mine; i += blockDim.x)
-        if (before + i < cap) out[before + i] = src[i];
-    if (s == 0 && threadIdx.x == 0) *out_count = (dropped && total <= cap) ? cap + 1 : total;
+    if (thr == nullptr) {
+        for (unsigned long long i = threadIdx.x; i < mine; i += blockDim.x)
+            if (before + i < cap) out[before + i] = src[i];
+        if (s == 0 && threadIdx.x == 0) *out_count = (dropped && total <= cap) ? cap + 1 : total;
+        return;
+    }
+    if (dropped) {  // every workgroup sees the same counters: nobody appends, one thread reports
+        if (s == 0 && threadIdx.x == 0) *out_count = cap + 1;
+        return;
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    for (unsigned long long base = 0; base < mine; base += blockDim.x) {  // uniform trip count per workgroup
+        const unsigned long long i = base + threadIdx.x;
+        smafa_hit h = {0, 0, 0};
+        bool keep = false;
+        if (i < mine) {
+            h = src[i];
+            keep = h.dist <= thr[h.query];
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (mask == 0ull) continue;
+        unsigned long long first = 0;
+        if (lane == 0) first = atomicAdd(out_count, (unsigned long long)__builtin_popcountll(mask));
+        first = ((unsigned long long)(uint32_t)__shfl((int)(first >> 32), 0, 64) << 32) |
+                (uint32_t)__shfl((int)(first & 0xffffffffull), 0, 64);
+        const unsigned long long slot = first + (unsigned long long)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (keep && slot < cap) out[slot] = h;
+    }
 }
 
 __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {

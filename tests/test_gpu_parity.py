@@ -7,6 +7,7 @@ size-independent properties in test_gpu_fullsize.py.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -17,6 +18,7 @@ from smafa_amd import _lib, synth
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NT_ASCII = np.frombuffer(b"ACGTN", dtype=np.uint8)
 
 
@@ -179,6 +181,42 @@ def test_kth_bound_modes(k, max_div):
     want = expected_with_k(full, k)
     assert got.tobytes() == want.tobytes()
     store.close()
+
+
+@pytest.mark.parametrize("alphabet,n_letters", [(0, 4), (1, 20)])
+def test_near_hit_probe_boundaries(alphabet, n_letters):
+    """k-th-distance modes with a loose or absent bound: a fixed-bound probe (bound 5 at L = 60) finishes the queries
+    with at least k rows within it, the rest take the tightening path as a compacted batch; queries sit exactly on
+    both sides of that boundary, with ties"""
+    rng = np.random.default_rng(31 + alphabet)
+    L, n = 60, 20000
+    s = rng.integers(0, n_letters, size=(n, L), dtype=np.uint8)
+    s[5000:5003] = s[17]              # 4 copies of row 17 in all: ties at distance 0 ...
+    qs = []
+    for subs in (0, 1, 4, 5, 5, 6, 6, 7, 12, 30):     # ... and queries at 0..30 substitutions from their subject
+        for base in (17, 400, 4242, 19999):
+            r = s[base].copy()
+            cols = rng.choice(L, size=subs, replace=False)
+            r[cols] = (r[cols] + 1 + rng.integers(0, n_letters - 1, size=subs)) % n_letters
+            qs.append(r)
+    qs += [rng.integers(0, n_letters, size=L, dtype=np.uint8) for _ in range(8)]  # no near subject at all
+    q = np.array(qs, dtype=np.uint8)
+    store = smafa_amd.SubjectStore(L, alphabet)
+    store.push(s)
+    for D in (None, 6, 20):
+        full = oracle.scan_codes(s, q, L if D is None else D)
+        for k in (1, 2, 4, 5, 60):
+            got = store.scan(q, max_divergence=D, max_num_hits=k)
+            assert got.tobytes() == expected_with_k(full, k).tobytes(), (D, k)
+    store.close()
+
+
+def test_device_resident_launch_all_modes():
+    """smafa_scan_launch (rows and count stay in HBM) in every mode — tests/device_launch_worker.py, a process of
+    its own because the device buffers come from torch, which has to initialise HIP before the library does"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "device_launch_worker.py")], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "device launch modes ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
 def test_capacity_error_reports_rows_needed():
