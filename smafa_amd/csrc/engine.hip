@@ -73,7 +73,8 @@ struct smafa_db {
     bool use_filter = true;  // exact lower-bound prefilter in the scan kernel (SMAFA_FILTER=0 disables)
     uint32_t tiles_override = 0;  // SMAFA_TILES
     bool lazy = true;             // filter-plane-resident kernel where it applies (SMAFA_LAZY=0 disables)
-    uint32_t wide_from = 3;       // words per plane from which scan_wide_kernel replaces the per-length kernels (SMAFA_WIDE_FROM)
+    bool wide_one = true;         // one-word stores (L <= 32) through scan_wide_kernel's two-plane level 2 (SMAFA_WIDE_ONE=0: lazy kernel)
+    uint32_t wide_from = 5;       // words per plane from which scan_wide_kernel replaces the per-length kernels (SMAFA_WIDE_FROM)
     // what the last launch used (smafa_last_scan_plan)
     uint32_t plan_lazy = 0, plan_tiles = 1, plan_qblocks = 1;
     int n_cu = 256;
@@ -216,26 +217,46 @@ static void launch_scan_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
 // measured 2 beats 1 for every store with W <= 2 even where it costs occupancy (profiles/r01_variant_tiles*.txt).
 // SMAFA_TILES=1|2|4 overrides (4: 2-plane store only).
 // The filter-plane-resident kernel wins where the prefilter prunes (sparse hits: +18 % aa, 5x less HBM traffic)
-// and loses 10-100 % where it cannot (profiles/r01_lazy_vs_resident.txt, r01_length_probe.txt).  Level 1 looks
-// at min(32, L) columns of one plane, where unrelated sequences differ in about half of them: it prunes while the
-// bound stays below about a quarter of those columns.  Chosen per launch from the initial bound, so best-hit scans
-// without --max-divergence (bound = L) and short sequences with a loose bound keep the all-planes kernel.
-static bool use_lazy(const smafa_db *db, uint32_t thr0) {
+// and loses 10-100 % where it cannot (profiles/r01_lazy_vs_resident.txt, r01_length_probe.txt).  Chosen per launch
+// from the initial bound, so best-hit scans without --max-divergence (bound = L) and short sequences with a loose
+// bound keep the all-planes kernel.
+// Level 1 looks at cols = min(32, L) columns of one plane, where unrelated sequences differ in about half: a subject
+// passes it with probability P(Binomial(cols, 1/2) <= bound).  The filter-plane-resident kernels pay off while a
+// wave's 1024 subjects rarely produce a pass, i.e. while that tail stays below ~2e-3 — for cols = 32 this is
+// bound <= 7, the measured crossover (profiles/r01_lazy_vs_resident.txt); short sequences need a tighter bound
+// (cols = 20: bound <= 3; cols = 12: bound 0 — L = 12 with bound 2 ran 3x slower through these kernels).
+static bool prefilter_prunes(const smafa_db *db, uint32_t bound) {
     const uint32_t cols = std::min<uint32_t>(32u, db->L);
-    return db->lazy && db->use_filter && db->W <= 2 && thr0 * 4u < cols;
+    if (bound >= cols) return false;
+    double term = 1.0, tail = 0.0;  // C(cols, k), summed for k = 0..bound
+    for (uint32_t k = 0; k <= bound; k++) {
+        tail += term;
+        term = term * (double)(cols - k) / (double)(k + 1);
+    }
+    for (uint32_t i = 0; i < cols; i++) tail *= 0.5;
+    return tail <= 2e-3;
 }
 
-// More than two words per plane (L > 64): scan_wide_kernel under the same rule — its levels 1 and 2 are the lazy
-// kernel's, with 16 subjects per lane whatever the length (measured 5-27 % faster than per-length instantiations
-// that keep every filter word resident, profiles/r01_length_probe.txt).  When the bound is too loose for the
-// prefilter, or it is switched off: scan_kernel (W <= 4) / scan_generic_kernel.  SMAFA_WIDE_FROM=n (>= 3) moves
-// the switch to n words.
+static bool use_lazy(const smafa_db *db, uint32_t thr0) {
+    const bool wide = db->W >= db->wide_from || (db->W == 1 && db->wide_one);
+    return db->lazy && db->use_filter && db->W <= 4 && !wide && prefilter_prunes(db, thr0);
+}
+
+// More than four words per plane (L > 128): scan_wide_kernel under the same rule — its levels 1 and 2 are the lazy
+// kernel's, with 16 subjects per lane whatever the length.  One-word stores (L <= 32) take it too: its level 2
+// folds a second plane, which a single filter word needs (up to 1.8x on sparse hits, equal elsewhere).  At W = 3, 4
+// it is 5-27 % faster than the per-length kernels on sparse hits but 2-5x slower on dense or closely related stores
+// (tools/dense_check.py: their level 2 folds every filter word and their full comparison keeps the tile in
+// registers), so those lengths keep them; SMAFA_WIDE_FROM=3 switches them over (profiles/r01_wide_vs_lazy.txt).
+// Bound too loose, or prefilter off: scan_kernel (W <= 4) / scan_generic_kernel.
 static bool use_wide(const smafa_db *db, uint32_t thr0) {
-    return db->lazy && db->use_filter && db->W >= db->wide_from && thr0 * 4u < 32u && wide_fits((int)db->PQ, (int)db->W);
+    const bool one = db->W == 1 && db->wide_one;
+    return db->lazy && db->use_filter && (db->W >= db->wide_from || one) && prefilter_prunes(db, thr0) &&
+           wide_fits((int)db->PQ, (int)db->W);
 }
 
 static uint32_t tiles_per_wave(const smafa_db *db, bool lazy) {
-    if (lazy) return 4u;  // W <= 2: 16 subjects per lane
+    if (lazy) return db->W >= 3 ? 2u : 4u;  // every filter word resident: 8 subjects per lane from 3 words on
     if (db->W > 2) return 1;
     if (db->tiles_override == 4) return db->P == 2 ? 4u : 2u;
     if (db->tiles_override == 1 || db->tiles_override == 2) return db->tiles_override;
@@ -244,17 +265,24 @@ static uint32_t tiles_per_wave(const smafa_db *db, bool lazy) {
 
 template <int PS, int PQ>
 static void launch_wide_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
-    if (a.hits == nullptr && a.k_tight == 1)
-        hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, true>), dim3(grid), dim3(256), 0, db->stream,
-                           reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a, db->W);
-    else
-        hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, false>), dim3(grid), dim3(256), 0, db->stream,
-                           reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a, db->W);
+    const bool seed = a.hits == nullptr && a.k_tight == 1;
+    const uint4 *planes = reinterpret_cast<const uint4 *>(db->d_planes);
+#define SMAFA_WIDE(SEED_, ONE_)                                                                                  \
+    hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, SEED_, ONE_>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a, \
+                       db->W)
+    if (db->W == 1) {
+        if (seed) SMAFA_WIDE(true, true);
+        else SMAFA_WIDE(false, true);
+    } else {
+        if (seed) SMAFA_WIDE(true, false);
+        else SMAFA_WIDE(false, false);
+    }
+#undef SMAFA_WIDE
 }
 
 static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid, uint32_t T,
                         bool lazy) {
-    if (lazy && db->W >= db->wide_from) {  // any length above 64 columns
+    if (lazy && (db->W >= db->wide_from || (db->W == 1 && db->wide_one))) {  // above 64 columns, or up to 32
         if (db->P == 2) return launch_wide_t<2, 3>(db, d_qrec, a, grid);
         if (db->P == 3) return launch_wide_t<3, 3>(db, d_qrec, a, grid);
         return launch_wide_t<5, 5>(db, d_qrec, a, grid);
@@ -267,6 +295,8 @@ static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanAr
     }
         SMAFA_LAZY(2, 3, 2, 4) SMAFA_LAZY(3, 3, 2, 4) SMAFA_LAZY(5, 5, 2, 4)
         SMAFA_LAZY(2, 3, 1, 4) SMAFA_LAZY(3, 3, 1, 4) SMAFA_LAZY(5, 5, 1, 4)
+        SMAFA_LAZY(2, 3, 3, 2) SMAFA_LAZY(3, 3, 3, 2) SMAFA_LAZY(5, 5, 3, 2)
+        SMAFA_LAZY(2, 3, 4, 2) SMAFA_LAZY(3, 3, 4, 2) SMAFA_LAZY(5, 5, 4, 2)
 #undef SMAFA_LAZY
     }
 #define SMAFA_CASE(PS_, PQ_, W_, T_)                          \
@@ -664,6 +694,7 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     }
     if (const char *lv = getenv("SMAFA_LAZY")) db->lazy = atoi(lv) != 0;
     if (const char *pv2 = getenv("SMAFA_TWO_PHASE")) db->two_phase = atoi(pv2) != 0;
+    if (const char *ov = getenv("SMAFA_WIDE_ONE")) db->wide_one = atoi(ov) != 0;
     if (const char *wv = getenv("SMAFA_WIDE_FROM")) db->wide_from = (uint32_t)std::max(3, atoi(wv));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) db->n_cu = prop.multiProcessorCount;

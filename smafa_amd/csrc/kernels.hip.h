@@ -615,8 +615,8 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
 }
 
 // ---------------------------------------------------------------------------------------------
-// L > 64 (more than 2 words per plane): the same three levels with the register footprint of a 64-column
-// store, for any length.  A lane keeps words 0 and 1 of the filter plane of its 16 subjects (4 wave tiles);
+// L > 64 (more than 2 words per plane) and L <= 32 (one word): the same three levels with the register footprint
+// of a 64-column store, for any length.  A lane keeps words 0 and 1 of the filter plane of its 16 subjects (4 wave tiles);
 // level 1 bounds word 0, level 2 the two-word fold (two subjects per popcount) — both exact lower bounds on the
 // distance, as in scan_lazy_kernel.  The full comparison (level 3, rare while the bound is small) streams the
 // surviving tile's planes from L2/HBM word by word and reads the query's words from LDS, so its registers do not
@@ -624,18 +624,25 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
 // instantiation per plane pair serves every length.  A chunk holds as many query records as fit 768 LDS vectors;
 // the first vector of each record ([f0 f1 bound ..]) is staged a second time in a dense array, so the hot loop
 // reads LDS at a compile-time stride whatever W is.
+// ONE (W == 1): a single filter word prunes too little (15 % of the queries reach level 3 at L = 30, bound 5), so
+// the second register word of a subject is word 0 of ANOTHER plane and level 2 bounds the two-plane fold — a
+// mismatch in either plane is a mismatching column, so it is still a lower bound on the distance.
 // ---------------------------------------------------------------------------------------------
 constexpr int kWideTiles = 4;
 constexpr int kWideStage = 768;  // uint4 per LDS buffer
+// queries per tile load on the dense path: 4 * group distances live in registers next to the tile's planes
+__host__ __device__ constexpr int wide_group(int ps) { return ps >= 5 ? 4 : ps == 3 ? 6 : 8; }
 __host__ __device__ constexpr bool wide_fits(int planes, int words) { return qrec_stride(planes, words) / 4 <= kWideStage; }
 
-template <int PS, int PQ, bool SEED>
+template <int PS, int PQ, bool SEED, bool ONE>
 __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restrict__ planes,
                                                            const uint32_t *__restrict__ qrec, ScanArgs a, uint32_t W) {
     constexpr int T = kWideTiles;
+    constexpr int kWideGroup = wide_group(PS);
     constexpr int NV = kWideStage / 256;
     constexpr int FP = filter_plane(PQ);
-    static_assert(FP < PS && PS <= PQ, "the filter plane must be one the subjects store");
+    constexpr int FP2 = FP == 0 ? 1 : 0;  // ONE: the second plane of level 2 (slot 2 of a one-word record)
+    static_assert(FP < PS && FP2 < PS && PS <= PQ, "the filter planes must be ones the subjects store");
     const uint32_t RS = (uint32_t)qrec_stride(PQ, (int)W);
     const uint32_t RV = RS / 4;
     const uint32_t BS = (uint32_t)bound_slot((int)W);
@@ -658,7 +665,7 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
         const bool live = tile0 + t < a.tile_end;
         const uint4 *src = planes + (size_t)(live ? tile0 + t : a.tile_begin) * tile_stride + (size_t)FP * W * 64 + lane;
         f[t][0] = src[0];
-        f[t][1] = src[64];
+        f[t][1] = ONE ? planes[(size_t)(live ? tile0 + t : a.tile_begin) * tile_stride + (size_t)FP2 * 64 + lane] : src[64];
     }
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
     const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
@@ -695,7 +702,25 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
             }
         }
     };
-    // full comparison of the query record at `rec` (LDS) against the 4 subjects this lane owns in `tile`
+    // report (or, in the seed pass, fold into the bound) the 4 subjects this lane owns in `tile`
+    auto finish = [&](uint32_t tile, uint32_t q, uint32_t U, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
+        const uint32_t subj0 = tile * kWaveTile + lane * 4u;
+        const uint32_t d[4] = {d0, d1, d2, d3};
+        if (SEED) {
+            uint32_t lo = 0xffffffffu;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (subj0 + k < a.n_subjects) lo = min(lo, d[k]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+            if (lane == 0 && lo < U) atomicMin(a.thr + q, lo);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, q, subj0 + k, d[k]);
+        }
+    };
+    // level 3: full comparison of the query record at `rec` (LDS) against the 4 subjects this lane owns in `tile`
     auto wide_compare = [&](uint32_t tile, const uint32_t *rec, uint32_t q) {
         const uint32_t U = ~rec[BS];
         const uint4 *src = planes + (size_t)tile * tile_stride + lane;
@@ -722,20 +747,60 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
             // (two-word steps with both loads in flight were measured: more registers, slower level 1)
             if (__ballot(min(min(d0, d1), min(d2, d3)) <= U) == 0ull) return;
         }
-        const uint32_t subj0 = tile * kWaveTile + lane * 4u;
-        const uint32_t d[4] = {d0, d1, d2, d3};
-        if (SEED) {
-            uint32_t lo = 0xffffffffu;
+        finish(tile, q, U, d0, d1, d2, d3);
+    };
+    // Dense neighbourhoods (the prefilter stopped paying for this wave): every pair gets the exact comparison.
+    // Streaming a tile from L2 once per query would cost P*W KB per (tile, query); instead a tile's words are
+    // loaded once per group of kWideGroup queries and the group's 4 * kWideGroup distances live in registers.
+    auto dense_walk = [&](const uint32_t *rec0, uint32_t nqc, uint32_t qc) {
+        for (uint32_t t = 0; t < (uint32_t)T; t++) {
+            const uint32_t tile = tile0 + t;
+            if (tile >= a.tile_end) break;
+            const uint4 *src = planes + (size_t)tile * tile_stride + lane;
+            for (uint32_t g = 0; g < nqc; g += kWideGroup) {
+                uint32_t d[kWideGroup][4];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (subj0 + k < a.n_subjects) lo = min(lo, d[k]);
+                for (int j = 0; j < kWideGroup; j++) d[j][0] = d[j][1] = d[j][2] = d[j][3] = 0;
+                for (uint32_t w = 0; w < W; w++) {
+                    uint4 v[PS];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
-            if (lane == 0 && lo < U) atomicMin(a.thr + q, lo);
-        } else {
+                    for (int p = 0; p < PS; p++) v[p] = src[((size_t)p * W + w) * 64];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, q, subj0 + k, d[k]);
+                    for (int j = 0; j < kWideGroup; j++) {
+                        const uint32_t *rec = rec0 + min(g + j, nqc - 1u) * RS;  // past the end: a copy, not reported
+                        uint32_t extra = 0;
+#pragma unroll
+                        for (int p = PS; p < PQ; p++) extra |= rec[qslot(PQ, (int)W, p, (int)w)];
+                        uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
+#pragma unroll
+                        for (int p = 0; p < PS; p++) {
+                            const uint32_t qv = rec[qslot(PQ, (int)W, p, (int)w)];
+                            m0 = or_xor(m0, v[p].x, qv);
+                            m1 = or_xor(m1, v[p].y, qv);
+                            m2 = or_xor(m2, v[p].z, qv);
+                            m3 = or_xor(m3, v[p].w, qv);
+                        }
+                        d[j][0] += __builtin_popcount(m0);
+                        d[j][1] += __builtin_popcount(m1);
+                        d[j][2] += __builtin_popcount(m2);
+                        d[j][3] += __builtin_popcount(m3);
+                    }
+                }
+                for (uint32_t j = 0; j < (uint32_t)kWideGroup && g + j < nqc; j++) {
+                    const uint32_t U = ~rec0[(g + j) * RS + BS];
+                    // dynamic j: pick the group's row with selects (the array stays in registers)
+                    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+#pragma unroll
+                    for (int jj = 0; jj < kWideGroup; jj++) {
+                        const bool mine = (uint32_t)jj == j;
+                        e0 = mine ? d[jj][0] : e0;
+                        e1 = mine ? d[jj][1] : e1;
+                        e2 = mine ? d[jj][2] : e2;
+                        e3 = mine ? d[jj][3] : e3;
+                    }
+                    if (__ballot(min(min(e0, e1), min(e2, e3)) <= U) != 0ull) finish(tile, qc + g + j, U, e0, e1, e2, e3);
+                }
+            }
         }
     };
 
@@ -759,11 +824,13 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
             const uint32_t *rec = reinterpret_cast<const uint32_t *>(&stage[buf][0]);
             uint32_t passes = 0, level1_passes = 0;
             const bool l1 = __builtin_amdgcn_readfirstlane((int)level1_on) != 0;
-            for (uint32_t i = 0; i < nqc; i++, rec += RS) {
-                uint32_t live = (1u << T) - 1u;  // dense neighbourhoods (no probe): every tile, exact comparison
-                if (probe) {
+            if (!probe) dense_walk(rec, nqc, qc);
+            for (uint32_t i = 0; probe && i < nqc; i++, rec += RS) {
+                uint32_t live = 0;
+                {
                     const uint4 head = heads[buf][i];  // [f0 f1 bound ..]: one LDS read at a constant stride
-                    const uint32_t qw0 = head.x, qw1 = head.y, nu = head.z;
+                    // [f0 f1 bound ..], or for one-word records [f0 bound g0 ..] (g = plane FP2)
+                    const uint32_t qw0 = head.x, qw1 = ONE ? head.z : head.y, nu = ONE ? head.y : head.z;
                     if (l1) {  // level 1: word 0 of the filter plane
                         uint32_t any1 = 0;
 #pragma unroll
@@ -779,7 +846,6 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
                         if (!go) continue;
                     }
                     // level 2: words 0 and 1 folded, two subjects per popcount
-                    live = 0;
 #pragma unroll
                     for (int t = 0; t < T; t++) {
                         const uint32_t m0 = or_xor(f[t][0].x ^ qw0, f[t][1].x, qw1);
