@@ -245,8 +245,8 @@ static bool use_lazy(const smafa_db *db, uint32_t thr0) {
 // More than four words per plane (L > 128): scan_wide_kernel under the same rule — its levels 1 and 2 are the lazy
 // kernel's, with 16 subjects per lane whatever the length.  One-word stores (L <= 32) take it too: its level 2
 // folds a second plane, which a single filter word needs (up to 1.8x on sparse hits, equal elsewhere).  At W = 3, 4
-// it is 5-27 % faster than the per-length kernels on sparse hits but 2-5x slower on dense or closely related stores
-// (tools/dense_check.py: their level 2 folds every filter word and their full comparison keeps the tile in
+// it is 8-25 % faster than the per-length kernels on sparse hits but 1.3-2x slower on dense or closely related
+// stores (tools/dense_check.py: their level 2 folds every filter word and their full comparison keeps the tile in
 // registers), so those lengths keep them; SMAFA_WIDE_FROM=3 switches them over (profiles/r01_wide_vs_lazy.txt).
 // Bound too loose, or prefilter off: scan_kernel (W <= 4) / scan_generic_kernel.
 static bool use_wide(const smafa_db *db, uint32_t thr0) {
@@ -267,16 +267,20 @@ template <int PS, int PQ>
 static void launch_wide_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
     const bool seed = a.hits == nullptr && a.k_tight == 1;
     const uint4 *planes = reinterpret_cast<const uint4 *>(db->d_planes);
-#define SMAFA_WIDE(SEED_, ONE_)                                                                                  \
-    hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, SEED_, ONE_>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a, \
-                       db->W)
-    if (db->W == 1) {
-        if (seed) SMAFA_WIDE(true, true);
-        else SMAFA_WIDE(false, true);
-    } else {
-        if (seed) SMAFA_WIDE(true, false);
-        else SMAFA_WIDE(false, false);
+    // resident filter words per subject: 1 = one-word store (plus word 0 of a second plane), else 3 (a fourth
+    // pushes the kernel past 128 VGPRs: measured spills, and one wave per SIMD less)
+    const uint32_t fw = db->W == 1 ? 1u : 3u;
+#define SMAFA_WIDE(FW_)                                                                                              \
+    if (fw == FW_) {                                                                                                 \
+        if (seed)                                                                                                    \
+            hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, true, FW_>), dim3(grid), dim3(256), 0, db->stream, planes,  \
+                               d_qrec, a, db->W);                                                                    \
+        else                                                                                                         \
+            hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, false, FW_>), dim3(grid), dim3(256), 0, db->stream, planes, \
+                               d_qrec, a, db->W);                                                                    \
+        return;                                                                                                      \
     }
+    SMAFA_WIDE(1) SMAFA_WIDE(3)
 #undef SMAFA_WIDE
 }
 

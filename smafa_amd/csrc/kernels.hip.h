@@ -615,10 +615,10 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
 }
 
 // ---------------------------------------------------------------------------------------------
-// L > 64 (more than 2 words per plane) and L <= 32 (one word): the same three levels with the register footprint
-// of a 64-column store, for any length.  A lane keeps words 0 and 1 of the filter plane of its 16 subjects (4 wave tiles);
-// level 1 bounds word 0, level 2 the two-word fold (two subjects per popcount) — both exact lower bounds on the
-// distance, as in scan_lazy_kernel.  The full comparison (level 3, rare while the bound is small) streams the
+// L > 64 (more than 2 words per plane) and L <= 32 (one word): the same three levels for any length.  A lane keeps
+// the first FW <= 4 words of the filter plane of its 16 subjects (4 wave tiles); level 1 bounds word 0, level 2 the
+// fold of the resident words (two subjects per popcount) — both exact lower bounds on the distance, as in
+// scan_lazy_kernel.  The full comparison (level 3, rare while the bound is small) streams the
 // surviving tile's planes from L2/HBM word by word and reads the query's words from LDS, so its registers do not
 // grow with W; it stops as soon as every subject of the wave is past the bound.  W is a runtime argument: one
 // instantiation per plane pair serves every length.  A chunk holds as many query records as fit 768 LDS vectors;
@@ -634,10 +634,14 @@ constexpr int kWideStage = 768;  // uint4 per LDS buffer
 __host__ __device__ constexpr int wide_group(int ps) { return ps >= 5 ? 4 : ps == 3 ? 6 : 8; }
 __host__ __device__ constexpr bool wide_fits(int planes, int words) { return qrec_stride(planes, words) / 4 <= kWideStage; }
 
-template <int PS, int PQ, bool SEED, bool ONE>
+template <int PS, int PQ, bool SEED, int FW>
 __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restrict__ planes,
                                                            const uint32_t *__restrict__ qrec, ScanArgs a, uint32_t W) {
     constexpr int T = kWideTiles;
+    constexpr bool ONE = FW == 1;          // one-word store: the second register word is word 0 of another plane
+    constexpr int NF = ONE ? 2 : FW;       // register words per subject
+    constexpr int HV = NF == 4 ? 2 : 1;    // vectors of a record that hold them: [f0 f1 bound f2 | f3 ..]
+    static_assert(FW >= 1 && FW <= 4, "1 (two planes of a one-word store) to 4 filter words resident");
     constexpr int kWideGroup = wide_group(PS);
     constexpr int NV = kWideStage / 256;
     constexpr int FP = filter_plane(PQ);
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
     const uint32_t BS = (uint32_t)bound_slot((int)W);
     const uint32_t chunk = min((uint32_t)kChunk, (uint32_t)kWideStage / RV);  // >= 1: the host checks wide_fits()
     __shared__ uint4 stage[2][kWideStage];
-    __shared__ uint4 heads[2][kChunk];  // first vector of every staged record, at a compile-time stride
+    __shared__ uint4 heads[2][kChunk][HV];  // leading vector(s) of every staged record, at a compile-time stride
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -659,14 +663,23 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
     const bool active = tile0 < a.tile_end;
     const size_t tile_stride = (size_t)PS * W * 64;
 
-    uint4 f[T][2];  // filter-plane words 0 and 1; tile slots past the range copy tile_begin (valid memory)
+    uint4 f[T][NF];  // filter-plane words 0..FW-1; tile slots past the range copy tile_begin (valid memory)
+    auto load_filter = [&]() {
 #pragma unroll
-    for (int t = 0; t < T; t++) {
-        const bool live = tile0 + t < a.tile_end;
-        const uint4 *src = planes + (size_t)(live ? tile0 + t : a.tile_begin) * tile_stride + (size_t)FP * W * 64 + lane;
-        f[t][0] = src[0];
-        f[t][1] = ONE ? planes[(size_t)(live ? tile0 + t : a.tile_begin) * tile_stride + (size_t)FP2 * 64 + lane] : src[64];
-    }
+        for (int t = 0; t < T; t++) {
+            const bool live = tile0 + t < a.tile_end;
+            const uint4 *src =
+                planes + (size_t)(live ? tile0 + t : a.tile_begin) * tile_stride + (size_t)FP * W * 64 + lane;
+            if (ONE) {
+                f[t][0] = src[0];
+                f[t][1] = planes[(size_t)(live ? tile0 + t : a.tile_begin) * tile_stride + (size_t)FP2 * 64 + lane];
+            } else {
+#pragma unroll
+                for (int w = 0; w < NF; w++) f[t][w] = src[w * 64];
+            }
+        }
+    };
+    load_filter();
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
     const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
 
@@ -698,7 +711,7 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
             const uint32_t idx = tid + v * 256;
             if (idx < nqc * RV) {
                 stage[buf][idx] = pre[v];
-                if (idx % RV == 0) heads[buf][idx / RV] = pre[v];
+                if (idx % RV < (uint32_t)HV) heads[buf][idx / RV][idx % RV] = pre[v];
             }
         }
     };
@@ -725,6 +738,7 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
         const uint32_t U = ~rec[BS];
         const uint4 *src = planes + (size_t)tile * tile_stride + lane;
         uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll 1
         for (uint32_t w = 0; w < W; w++) {
             uint32_t extra = 0;
 #pragma unroll
@@ -761,6 +775,7 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
                 uint32_t d[kWideGroup][4];
 #pragma unroll
                 for (int j = 0; j < kWideGroup; j++) d[j][0] = d[j][1] = d[j][2] = d[j][3] = 0;
+#pragma unroll 1
                 for (uint32_t w = 0; w < W; w++) {
                     uint4 v[PS];
 #pragma unroll
@@ -824,13 +839,16 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
             const uint32_t *rec = reinterpret_cast<const uint32_t *>(&stage[buf][0]);
             uint32_t passes = 0, level1_passes = 0;
             const bool l1 = __builtin_amdgcn_readfirstlane((int)level1_on) != 0;
-            if (!probe) dense_walk(rec, nqc, qc);
+            if (!probe) {
+                dense_walk(rec, nqc, qc);
+                load_filter();  // not kept across the walk: its registers hold the group's distances meanwhile
+            }
             for (uint32_t i = 0; probe && i < nqc; i++, rec += RS) {
                 uint32_t live = 0;
                 {
-                    const uint4 head = heads[buf][i];  // [f0 f1 bound ..]: one LDS read at a constant stride
-                    // [f0 f1 bound ..], or for one-word records [f0 bound g0 ..] (g = plane FP2)
-                    const uint32_t qw0 = head.x, qw1 = ONE ? head.z : head.y, nu = ONE ? head.y : head.z;
+                    const uint4 head = heads[buf][i][0];  // one LDS read at a constant stride
+                    // [f0 f1 bound f2 | f3 ..]; one-word records: [f0 bound g0 ..] (g = plane FP2)
+                    const uint32_t qw0 = head.x, nu = ONE ? head.y : head.z;
                     if (l1) {  // level 1: word 0 of the filter plane
                         uint32_t any1 = 0;
 #pragma unroll
@@ -845,13 +863,23 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
                         level1_passes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(level1_passes + (go ? 1u : 0u)));
                         if (!go) continue;
                     }
-                    // level 2: words 0 and 1 folded, two subjects per popcount
+                    // level 2: the resident words folded, two subjects per popcount
+                    uint32_t qf[NF];
+                    qf[0] = qw0;
+                    qf[1] = ONE ? head.z : head.y;
+                    if (NF >= 3) qf[2] = head.w;
+                    if (NF >= 4) qf[3] = heads[buf][i][HV - 1].x;
 #pragma unroll
                     for (int t = 0; t < T; t++) {
-                        const uint32_t m0 = or_xor(f[t][0].x ^ qw0, f[t][1].x, qw1);
-                        const uint32_t m1 = or_xor(f[t][0].y ^ qw0, f[t][1].y, qw1);
-                        const uint32_t m2 = or_xor(f[t][0].z ^ qw0, f[t][1].z, qw1);
-                        const uint32_t m3 = or_xor(f[t][0].w ^ qw0, f[t][1].w, qw1);
+                        uint32_t m0 = f[t][0].x ^ qf[0], m1 = f[t][0].y ^ qf[0];
+                        uint32_t m2 = f[t][0].z ^ qf[0], m3 = f[t][0].w ^ qf[0];
+#pragma unroll
+                        for (int w = 1; w < NF; w++) {
+                            m0 = or_xor(m0, f[t][w].x, qf[w]);
+                            m1 = or_xor(m1, f[t][w].y, qf[w]);
+                            m2 = or_xor(m2, f[t][w].z, qf[w]);
+                            m3 = or_xor(m3, f[t][w].w, qf[w]);
+                        }
                         const uint32_t sign =
                             SMAFA_AND_PAIR ? ((__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu))
                                            : (or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
