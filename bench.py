@@ -189,10 +189,11 @@ def main() -> None:
             "streamed_bytes_per_subject": int(sb),
             "kernel_streamed_GBs": streamed / k_med / 1e6,
             "kernel_frac_of_peak": streamed / k_med / 1e6 / HBM_PEAK_GBS,
-            "kernel_algorithmic_GBs": N * L / k_med / 1e6,
+            "kernel_algorithmic_GBs": N * L * (8 if args.alphabet == "aa" else int(info.planes)) / 8 / k_med / 1e6,
             "plan": splan,
             "note": "one query per DB pass; streamed = bit-plane bytes the kernel actually reads per subject (the "
-                    "prefilter's plane only when the other planes are fetched on demand); algorithmic = %d B/subject" % L,
+                    "prefilter's plane only when the other planes are fetched on demand); algorithmic = %g B/subject"
+                    % (L * (8 if args.alphabet == "aa" else int(info.planes)) / 8),
         }
         one.close()
 
@@ -249,7 +250,9 @@ def main() -> None:
         q_total = Q * world
         value = q_total * args.steps / elapsed
         pairs_per_launch = Q * N
-        alg_bytes = pairs_per_launch * L  # B_s = L x 8 bits / 8 = 60 B per (query, subject)
+        # B_s = L x bits per symbol / 8 — aa 8 bits (60 B), nt 2 bits (15 B), nt with N 3 planes (22.5 B)
+        sym_bits = 8 if args.alphabet == "aa" else int(info.planes)
+        alg_bytes = pairs_per_launch * L * sym_bits // 8
         achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
         filt = os.environ.get("SMAFA_FILTER", "1") != "0"  # the timed steps run with the library default
         W_, P_ = info.words_per_plane, info.planes
@@ -306,11 +309,11 @@ def main() -> None:
                                   "WRITE_SIZE, bytes per launch)" if traffic else None,
                 "kernel_ms_avg": kernel_ms_avg,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "algorithmic bytes = queries x subjects x %d B (SURVEY 8d). The kernel keeps a 1024-subject "
+                "note": "algorithmic bytes = queries x subjects x %g B (SURVEY 8d). The kernel keeps a 1024-subject "
                         "tile in registers and walks a whole query block over it, so the store is streamed from HBM "
                         "once per query block, not once per query (see `traffic`): frac > 1 is register-level reuse "
                         "plus the exact lower-bound prefilter, NOT HBM efficiency. The real ceiling of this kernel "
-                        "is VALU issue (see `valu`); the HBM-bound form (one query per pass) is in `stream`." % L,
+                        "is VALU issue (see `valu`); the HBM-bound form (one query per pass) is in `stream`." % (L * sym_bits / 8),
                 "valu": {
                     "prefilter": filt,
                     "plan": plan,
