@@ -580,6 +580,30 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
                             for (int t = 0; t < T; t++)
                                 if (__ballot((int32_t)tsign[t] < 0) != 0ull) live |= 1u << t;
                             live = (uint32_t)__builtin_amdgcn_readfirstlane((int)live);
+                            if (kPair) {
+                                // The two-subject AND passes whenever ONE of the pair is close on this plane (a
+                                // relative of the query next to anything): before fetching a tile, look at its
+                                // subjects one by one.  Rare path: recomputing the masks is cheaper than keeping them.
+#pragma unroll
+                                for (int t = 0; t < T; t++) {
+                                    if ((live >> t) & 1u) {
+                                        uint32_t m0 = f[t][0].x ^ qw[0], m1 = f[t][0].y ^ qw[0];
+                                        uint32_t m2 = f[t][0].z ^ qw[0], m3 = f[t][0].w ^ qw[0];
+#pragma unroll
+                                        for (int w = 1; w < W; w++) {
+                                            m0 = or_xor(m0, f[t][w].x, qw[qslot(PQ, W, FP, w)]);
+                                            m1 = or_xor(m1, f[t][w].y, qw[qslot(PQ, W, FP, w)]);
+                                            m2 = or_xor(m2, f[t][w].z, qw[qslot(PQ, W, FP, w)]);
+                                            m3 = or_xor(m3, f[t][w].w, qw[qslot(PQ, W, FP, w)]);
+                                        }
+                                        const uint32_t each = or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
+                                                                  __builtin_popcount(m2) + nu) |
+                                                              (__builtin_popcount(m3) + nu);
+                                        if (__ballot((int32_t)each < 0) == 0ull) live &= ~(1u << t);
+                                    }
+                                }
+                                live = (uint32_t)__builtin_amdgcn_readfirstlane((int)live);
+                            }
                             while (live) {  // ONE copy of the comparison code, whatever T is
                                 const uint32_t t = (uint32_t)__builtin_ctz(live);
                                 live &= live - 1;
@@ -888,6 +912,27 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
                         if (__ballot((int32_t)sign < 0) != 0ull) live |= 1u << t;
                     }
                     live = (uint32_t)__builtin_amdgcn_readfirstlane((int)live);
+                    if (SMAFA_AND_PAIR && live != 0) {  // subjects one by one before a tile is streamed (see scan_lazy_kernel)
+#pragma unroll
+                        for (int t = 0; t < T; t++) {
+                            if ((live >> t) & 1u) {
+                                uint32_t m0 = f[t][0].x ^ qf[0], m1 = f[t][0].y ^ qf[0];
+                                uint32_t m2 = f[t][0].z ^ qf[0], m3 = f[t][0].w ^ qf[0];
+#pragma unroll
+                                for (int w = 1; w < NF; w++) {
+                                    m0 = or_xor(m0, f[t][w].x, qf[w]);
+                                    m1 = or_xor(m1, f[t][w].y, qf[w]);
+                                    m2 = or_xor(m2, f[t][w].z, qf[w]);
+                                    m3 = or_xor(m3, f[t][w].w, qf[w]);
+                                }
+                                const uint32_t each = or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
+                                                          __builtin_popcount(m2) + nu) |
+                                                      (__builtin_popcount(m3) + nu);
+                                if (__ballot((int32_t)each < 0) == 0ull) live &= ~(1u << t);
+                            }
+                        }
+                        live = (uint32_t)__builtin_amdgcn_readfirstlane((int)live);
+                    }
                     if (live == 0) continue;
                     passes++;
                 }
