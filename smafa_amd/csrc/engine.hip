@@ -394,11 +394,11 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     if (k_tight) scratch_rows = std::max<uint64_t>(scratch_rows, std::min<uint64_t>((uint64_t)nq * 128u, 1ull << 27));
     const uint64_t shard_cap = (scratch_rows + kShards - 1) / kShards + 256;
     int src = db->shard_rows.ensure(shard_cap * kShards * sizeof(smafa_hit));
-    if (!src) src = db->shard_counts.ensure(kShards * sizeof(unsigned long long));
+    if (!src) src = db->shard_counts.ensure((size_t)kShards * kCountStride * sizeof(unsigned long long));
     if (src) return src;
     smafa_hit *d_shards = db->shard_rows.as<smafa_hit>();
     unsigned long long *d_shard_counts = db->shard_counts.as<unsigned long long>();
-    HIP_TRY(hipMemsetAsync(d_shard_counts, 0, kShards * sizeof(unsigned long long), db->stream));
+    HIP_TRY(hipMemsetAsync(d_shard_counts, 0, (size_t)kShards * kCountStride * sizeof(unsigned long long), db->stream));
     const uint32_t thr0 = std::min<uint32_t>(max_div, db->L);  // a distance never exceeds seq_len
     if (k_tight)
         hipLaunchKernelGGL(fill_u32_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream,
@@ -581,8 +581,8 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
     bool collected = false;
     // k-th-distance modes whose bound is loose or absent (`smafa query` without --max-divergence): the scan would
     // run the all-planes kernel until each query's running bound has tightened.  Most queries of real inputs have
-    // their k nearest subjects within a few mismatches, so first ask the cheap question — one fixed-bound launch
-    // at a bound the prefilter prunes well at (d0).  A query with at least k rows within d0 is finished:
+    // their k nearest subjects within a few mismatches, so first ask the cheap question — a scan whose bound starts
+    // at a value the prefilter prunes well at (d0).  A query with at least k rows within d0 is finished:
     // its k-th smallest distance is <= d0, so every row it may print is among them.  Only the other queries take
     // the tightening path, as a compacted batch.  Exact either way; when no query is finished the probe costs one
     // fast launch (~10 % of the slow path), when d0 already overflows the buffer it is abandoned.
@@ -595,7 +595,9 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
         n_queries >= 16) {
         const uint32_t nq = (uint32_t)n_queries;
         unsigned long long count = 0;
-        rc = scan_range(db, &db->scratch_q, 0, nq, d0, 0, db->hits.as<smafa_hit>(), db->hits_cap(),
+        // the probe itself runs in the tightening mode (bound d0, lowered to each query's k-th distance as the scan
+        // proceeds), so on dense stores only the rows within the final bound come back, not every pair within d0
+        rc = scan_range(db, &db->scratch_q, 0, nq, d0, k_mode, db->hits.as<smafa_hit>(), db->hits_cap(),
                         db->count.as<unsigned long long>());
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(&count, db->count.p, sizeof count, hipMemcpyDeviceToHost, db->stream));

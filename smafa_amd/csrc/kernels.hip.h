@@ -46,6 +46,8 @@ constexpr int kWaveTile = 256;  // subjects per wave tile
 constexpr int kWgWaves = 4;     // waves per workgroup
 constexpr int kChunk = 64;      // queries staged in LDS at a time
 constexpr uint32_t kShards = 64;  // row-append segments (and counters) per scan
+constexpr uint32_t kCountStride = 32;  // u64 slots between two shard counters: one counter per 256 B, so that atomics
+                                       // on different shards do not queue up behind each other on one cache line
 // __launch_bounds__ second argument (waves per SIMD the register budget must allow) for the scan kernel:
 // the subject words held per lane plus ~40 working registers, mapped through the gfx950 allocation steps.
 __host__ __device__ constexpr int scan_min_waves(int ps, int w, int t) {
@@ -115,8 +117,18 @@ __device__ __forceinline__ uint32_t ld_relaxed(const uint32_t *p) {
 // subject within the true bound passes `dist <= thr` whenever it is visited.
 __device__ __forceinline__ void emit(const ScanArgs &a, uint32_t q, uint32_t subject, uint32_t dist) {
     if (a.hits) {
+        // One atomic per wave, not per row: the lanes that got here together (a wave works on one query at a
+        // time, so they all append for the same query) take consecutive slots.  On dense stores most lanes
+        // of a wave have a row, and 64 same-address atomics in a row were the bottleneck of the scan.
+        const unsigned long long together = __ballot(1);  // the active lanes
+        const uint32_t lane = __lane_id();
+        const int leader = __builtin_ctzll(together);
         const uint32_t shard = blockIdx.x % kShards;
-        unsigned long long slot = atomicAdd(a.count + shard, 1ull);
+        unsigned long long base = 0;
+        if ((int)lane == leader) base = atomicAdd(a.count + (size_t)shard * kCountStride, (unsigned long long)__builtin_popcountll(together));
+        base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), leader, 64) << 32) |
+               (uint32_t)__shfl((int)(base & 0xffffffffull), leader, 64);
+        const unsigned long long slot = base + (unsigned long long)__builtin_popcountll(together & ((1ull << lane) - 1ull));
         if (slot < a.shard_cap) {
             smafa_hit h;
             h.query = q;
@@ -1139,12 +1151,13 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const smafa_hit *shar
     unsigned long long before = 0, total = 0;
     bool dropped = false;
     for (uint32_t i = 0; i < kShards; i++) {
-        const unsigned long long c = counts[i];
+        const unsigned long long c = counts[(size_t)i * kCountStride];
         if (c > shard_cap) dropped = true;
         if (i < s) before += c < shard_cap ? c : shard_cap;
         total += c;
     }
-    const unsigned long long mine = counts[s] < shard_cap ? counts[s] : shard_cap;
+    const unsigned long long cs = counts[(size_t)s * kCountStride];
+    const unsigned long long mine = cs < shard_cap ? cs : shard_cap;
     const smafa_hit *src = shards + (size_t)s * shard_cap;
     if (thr == nullptr) {
         for (unsigned long long i = threadIdx.x; i < mine; i += blockDim.x)
