@@ -138,7 +138,8 @@ __device__ __forceinline__ void emit(const ScanArgs &a, uint32_t q, uint32_t sub
         }
     }
     if (a.k_tight == 1) {
-        atomicMin(a.thr + q, dist);
+        // ties with the current minimum are the common case once the bound has settled: they need no atomic
+        if (dist < ld_relaxed(a.thr + q)) atomicMin(a.thr + q, dist);
     } else if (a.k_tight >= 2) {
         uint32_t *c = a.cnt + (size_t)q * a.cnt_stride;
         atomicAdd(c + dist, 1u);
