@@ -1,0 +1,78 @@
+"""Randomised differential soak on the GPU box: random shapes, alphabets, letter skews, family structure, bounds,
+k-th modes AND kernel forms (the SMAFA_* switches are drawn per store), HIP scan vs the oracle, for SOAK_SECONDS.
+Prints the failing configuration and exits 1 on the first difference.  (Checker only: the oracle is test infrastructure.)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import oracle, smafa_amd
+
+def expected_with_k(all_hits, k):
+    out, i = [], 0
+    while i < len(all_hits):
+        j = i
+        while j < len(all_hits) and all_hits[j]["query"] == all_hits[i]["query"]:
+            j += 1
+        grp = all_hits[i:j]
+        kth = grp[k - 1]["dist"] if len(grp) >= k else 0xFFFFFFFF
+        out.append(grp[grp["dist"] <= kth])
+        i = j
+    return np.concatenate(out) if out else all_hits[:0]
+
+seed0 = int(os.environ.get("SOAK_SEED", str(int(time.time()))))
+budget = float(os.environ.get("SOAK_SECONDS", "120"))
+oracle.build()
+t_end, rounds, scans = time.time() + budget, 0, 0
+SWITCHES = {"SMAFA_FILTER": ["1", "1", "1", "0"], "SMAFA_LAZY": ["1", "1", "0"], "SMAFA_TILES": ["", "1", "2", "4"],
+            "SMAFA_NT_PLANES": ["", "", "3"], "SMAFA_WIDE_FROM": ["5", "5", "3"], "SMAFA_WIDE_ONE": ["1", "1", "0"],
+            "SMAFA_TWO_PHASE": ["1", "1", "0"]}
+print("soak seed", seed0, flush=True)
+while time.time() < t_end:
+    rng = np.random.default_rng(seed0 + rounds)
+    rounds += 1
+    alphabet = int(rng.integers(0, 2))
+    n_letters = int(rng.choice([2, 4, 5] if alphabet == 0 else [2, 4, 20, 28]))
+    L = int(rng.choice([1, 2, 7, 12, 20, 31, 32, 33, 60, 60, 60, 64, 65, 90, 96, 128, 129, 150, 200, 257]))
+    n = int(rng.choice([1, 3, 255, 256, 257, 1000, 4097, 20000]))
+    nq = int(rng.choice([1, 2, 17, 64, 65, 300]))
+    env = {k: str(rng.choice(v)) for k, v in SWITCHES.items()}
+    for k, v in env.items():
+        if v: os.environ[k] = v
+        else: os.environ.pop(k, None)
+    # subjects: unrelated, or families around a few roots (dense / related neighbourhoods), plus exact copies
+    mode = int(rng.integers(0, 3))
+    if mode == 0:
+        s = rng.integers(0, n_letters, size=(n, L), dtype=np.uint8)
+    else:
+        roots = rng.integers(0, n_letters, size=(max(1, n // int(rng.choice([5, 50, 500]))), L), dtype=np.uint8)
+        s = roots[rng.integers(0, len(roots), size=n)].copy()
+        mut = rng.random(size=s.shape) < float(rng.choice([0.02, 0.1, 0.25]))
+        s[mut] = rng.integers(0, n_letters, size=int(mut.sum()), dtype=np.uint8)
+    if n > 4:
+        s[n // 2] = s[1]; s[n - 1] = s[1]
+    q = s[rng.integers(0, n, size=nq)].copy()
+    for r in q:
+        for _ in range(int(rng.integers(0, min(L, 9) + 1))):
+            r[rng.integers(0, L)] = rng.integers(0, n_letters)
+    if nq > 3:
+        q[0] = rng.integers(0, n_letters, size=L, dtype=np.uint8)
+    store = smafa_amd.SubjectStore(L, alphabet)
+    for lo in range(0, n, max(1, n // int(rng.integers(1, 4)))):  # appended in 1-3 pieces
+        pass
+    cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=int(rng.integers(0, 3)))]))
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        store.push(s[a:b])
+    for _ in range(3):
+        D = None if rng.random() < 0.25 else int(rng.integers(0, L + 1)) if rng.random() < 0.3 else int(rng.integers(0, min(L, 9) + 1))
+        k = None if rng.random() < 0.4 else int(rng.choice([1, 1, 2, 3, 10, 400]))
+        if D is None and k is None:
+            D = int(rng.integers(0, min(L, 6) + 1))
+        got = store.scan(q, max_divergence=D, max_num_hits=k)
+        full = oracle.scan_codes(s, q, L if D is None else D)
+        want = full if k is None else expected_with_k(full, k)
+        scans += 1
+        if got.tobytes() != want.tobytes():
+            print("MISMATCH round", rounds - 1, "seed", seed0, dict(alphabet=alphabet, n_letters=n_letters, L=L, n=n, nq=nq, mode=mode, D=D, k=k,
+                  env=env, got=len(got), want=len(want), plan=store.last_scan_plan()), flush=True)
+            sys.exit(1)
+    store.close()
+print("soak ok: %d stores, %d scans in %.0f s" % (rounds, scans, budget), flush=True)
