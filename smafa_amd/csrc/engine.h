@@ -18,6 +18,9 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div, uint32_t max_num_hits,
                  std::vector<smafa_hit> &out);
 
+// Bring the HIP runtime and the device context up (a few hundred ms the first time in a process).  The drivers call it
+// on a helper thread while they read and decode their input; failures are ignored here — the first real call reports.
+void warm_device(int device);
 // Forget the subjects but keep the handle's device memory, stream and scratch (cluster's per-batch candidate store).
 int db_clear(smafa_db *db);
 // selection rules of src/lib.rs:241-315 (see smafa_select_rows in the public header)

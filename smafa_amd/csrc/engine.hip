@@ -555,6 +555,13 @@ static int collect_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_
     return fetch_rows(db, count, q_begin, q_end, out);
 }
 
+void warm_device(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return;
+    if (hipSetDevice(device) != hipSuccess) return;
+    (void)hipFree(nullptr);  // forces the context
+}
+
 // Rows past n in the last tile keep their old bits; every kernel tests subject < n_subjects before it reports or
 // tightens a bound, exactly as it does for the zero padding of a fresh store.
 int db_clear(smafa_db *db) {

@@ -11,6 +11,11 @@
 // Version 3 is this build's container for stores the reference cannot express (amino acids):
 //   varint(3) varint(alphabet) varint(n) varint(seq_len) then n*seq_len raw code bytes.
 // The reference rejects it with its "Unsupported db file version: 3." panic, as it should.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cerrno>
 #include <cstdio>
@@ -52,16 +57,47 @@ bool get_varint(const uint8_t *buf, size_t len, size_t &pos, int max_bytes, uint
     return false;
 }
 
-int read_file(const char *path, std::vector<uint8_t> &out) {
-    FILE *f = fopen(path, "rb");
-    if (!f) return set_error(SMAFA_ERR_IO, "%s: %s", path, strerror(errno));
-    out.clear();
+// The bytes of a file: regular files are mapped (no copy — a 10M-row store is 460 MB, and the worker threads of the
+// decoder fault its pages in side by side); anything else (pipes, /dev/stdin) is read into a buffer.
+struct FileBytes {
+    const uint8_t *p = nullptr;
+    size_t len = 0;
+    void *map = nullptr;
+    std::vector<uint8_t> buf;
+    ~FileBytes() {
+        if (map) munmap(map, len);
+    }
+};
+
+int read_file(const char *path, FileBytes &out) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return set_error(SMAFA_ERR_IO, "%s: %s", path, strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            close(fd);
+            out.map = m;
+            out.p = (const uint8_t *)m;
+            out.len = (size_t)st.st_size;
+            return SMAFA_OK;
+        }
+    }
     std::vector<uint8_t> chunk(1u << 20);
-    size_t r;
-    while ((r = fread(chunk.data(), 1, chunk.size(), f)) > 0) out.insert(out.end(), chunk.begin(), chunk.begin() + r);
-    const bool bad = ferror(f);
-    fclose(f);
-    if (bad) return set_error(SMAFA_ERR_IO, "%s: read error", path);
+    for (;;) {
+        const ssize_t r = read(fd, chunk.data(), chunk.size());
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            const int e = errno;
+            close(fd);
+            return set_error(SMAFA_ERR_IO, "%s: %s", path, strerror(e));
+        }
+        if (r == 0) break;
+        out.buf.insert(out.buf.end(), chunk.begin(), chunk.begin() + r);
+    }
+    close(fd);
+    out.p = out.buf.data();
+    out.len = out.buf.size();
     return SMAFA_OK;
 }
 
@@ -145,9 +181,15 @@ int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t
     *codes = nullptr;
     *n = 0;
     *seq_len = 0;
-    std::vector<uint8_t> buf;
-    int rc = read_file(path, buf);
+    FileBytes file;
+    int rc = read_file(path, file);
     if (rc) return rc;
+    struct {  // the decoder below was written against a vector: same two accessors
+        const uint8_t *p_;
+        size_t n_;
+        const uint8_t *data() const { return p_; }
+        size_t size() const { return n_; }
+    } buf = {file.p, file.len};
     // src/lib.rs:214 decodes the version from &buffer[0..4]
     if (buf.size() < 4)
         return set_error(SMAFA_ERR_PANIC, "range end index 4 out of range for slice of length %zu", buf.size());

@@ -211,6 +211,11 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
     FreeGuard codes_guard;
     uint8_t *codes = nullptr;
     const double t_start = now_seconds();
+    struct Warm {  // device bring-up overlaps the file read and decode; joined before the first device call or return
+        std::thread t;
+        explicit Warm(int device) : t(warm_device, device) {}
+        ~Warm() { if (t.joinable()) t.join(); }
+    } warm(device);
     log_line(1, "Decoding db file \"%s\"", db_path);  // src/lib.rs:206
     int rc = smafa_dbfile_read(db_path, &alphabet, &codes, &n, &L);  // src/lib.rs:208-218
     if (rc) return rc;
@@ -223,6 +228,7 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
 
     DbGuard guard;
     if (n > 0) {
+        warm.t.join();
         const double t0 = now_seconds();
         rc = smafa_db_create(&guard.db, device, alphabet, L);
         if (rc) return rc;
@@ -347,8 +353,10 @@ static int cluster_run(const char *input_fasta, uint32_t max_divergence, int out
     int rc = SMAFA_OK;
     log_line(1, "Clustering ..");  // src/cluster.rs:33
 
+    std::thread warm(warm_device, device);  // device bring-up overlaps the parse
     BulkRecords recs;
     rc = load_records_bulk(input_fasta, alphabet, true, recs);  // src/cluster.rs:28,35-43 for every record
+    warm.join();
     if (rc) return rc;
     std::vector<uint8_t> &raw = recs.raw, &codes = recs.codes;
     const uint64_t n = recs.n;

@@ -7,6 +7,10 @@
 //    (tests/data/subjects.fa); FASTQ is the 4-line form.
 #include "fastx.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cerrno>
@@ -29,23 +33,37 @@ int FastxReader::open(const char *path) {
     if (got >= 6 && magic[0] == 0xfd && magic[1] == '7' && magic[2] == 'z' && magic[3] == 'X' && magic[4] == 'Z')
         return set_error(SMAFA_ERR_FORMAT, "%s: xz input is not supported by this build", path);
     data_.clear();
+    if (map_) munmap(map_, size_);
+    map_ = nullptr;
+    base_ = nullptr;
+    size_ = 0;
     const bool gz = got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b;
-    if (!gz) {  // plain file: one read into a buffer of the file's size
-        f = fopen(path, "rb");
-        if (!f) return set_error(SMAFA_ERR_IO, "%s: cannot open", path);
-        if (fseek(f, 0, SEEK_END) == 0) {
-            const long sz = ftell(f);
-            if (sz > 0) data_.resize((size_t)sz);
-            rewind(f);
+    if (!gz) {  // plain file: mapped when it is a regular file, otherwise read to the end
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return set_error(SMAFA_ERR_IO, "%s: cannot open", path);
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                map_ = m;
+                base_ = (const uint8_t *)m;
+                size_ = (size_t)st.st_size;
+            }
         }
-        size_t have = data_.empty() ? 0 : fread(data_.data(), 1, data_.size(), f);
-        data_.resize(have);
-        std::vector<uint8_t> more(1u << 20);  // whatever a growing or unseekable file still has
-        size_t r;
-        while ((r = fread(more.data(), 1, more.size(), f)) > 0) data_.insert(data_.end(), more.begin(), more.begin() + r);
-        const bool bad = ferror(f);
-        fclose(f);
-        if (bad) return set_error(SMAFA_ERR_IO, "%s: read error", path);
+        if (!map_) {
+            std::vector<uint8_t> more(1u << 20);
+            for (;;) {
+                const ssize_t r = read(fd, more.data(), more.size());
+                if (r < 0) {
+                    if (errno == EINTR) continue;
+                    close(fd);
+                    return set_error(SMAFA_ERR_IO, "%s: read error", path);
+                }
+                if (r == 0) break;
+                data_.insert(data_.end(), more.begin(), more.begin() + r);
+            }
+        }
+        close(fd);
     } else {
         gzFile g = gzopen(path, "rb");
         if (!g) return set_error(SMAFA_ERR_IO, "%s: cannot open", path);
@@ -62,17 +80,25 @@ int FastxReader::open(const char *path) {
         }
         gzclose(g);
     }
-    if (data_.empty()) return set_error(SMAFA_ERR_FORMAT, "valid path/file expected: %s is empty", path);
-    if (data_[0] != '>' && data_[0] != '@')
+    if (!map_) {
+        base_ = data_.data();
+        size_ = data_.size();
+    }
+    if (size_ == 0) return set_error(SMAFA_ERR_FORMAT, "valid path/file expected: %s is empty", path);
+    if (base_[0] != '>' && base_[0] != '@')
         return set_error(SMAFA_ERR_FORMAT, "valid path/file expected: %s does not start with '>' or '@'", path);
-    fastq_ = data_[0] == '@';
+    fastq_ = base_[0] == '@';
     pos_ = 0;
     return SMAFA_OK;
 }
 
+FastxReader::~FastxReader() {
+    if (map_) munmap(map_, size_);
+}
+
 int FastxReader::next(FastxRecord &rec) {
-    const uint8_t *d = data_.data();
-    const size_t n = data_.size();
+    const uint8_t *d = base_;
+    const size_t n = size_;
     auto eol = [&](size_t from) {
         const void *p = from < n ? memchr(d + from, '\n', n - from) : nullptr;
         return p ? (size_t)((const uint8_t *)p - d) : n;
@@ -229,9 +255,8 @@ int load_records_bulk(const char *path, int alphabet, bool want_raw, BulkRecords
     FastxReader reader;
     int rc = reader.open(path);
     if (rc) return rc;
-    const std::vector<uint8_t> &data = reader.buffer();
-    const uint8_t *d = data.data();
-    const size_t n = data.size();
+    const uint8_t *d = reader.data();
+    const size_t n = reader.size();
     unsigned n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (reader.is_fastq() || n < (32u << 20) || n_threads < 2) {
         // sequential path: FastxReader record by record

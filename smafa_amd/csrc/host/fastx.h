@@ -23,10 +23,20 @@ class FastxReader {
     // 1 = record, 0 = end of input, negative = error code
     int next(FastxRecord &rec);
     // the whole (decompressed) input and its format, for the bulk loader
-    const std::vector<uint8_t> &buffer() const { return data_; }
+    const uint8_t *data() const { return base_; }
+    size_t size() const { return size_; }
     bool is_fastq() const { return fastq_; }
+    FastxReader() = default;
+    FastxReader(const FastxReader &) = delete;
+    FastxReader &operator=(const FastxReader &) = delete;
+    ~FastxReader();
 
   private:
+    // plain regular files are mapped (no copy; the bulk loader's threads fault the pages in side by side);
+    // gzip input and pipes are read into data_
+    const uint8_t *base_ = nullptr;
+    size_t size_ = 0;
+    void *map_ = nullptr;
     std::vector<uint8_t> data_;
     std::vector<uint8_t> seq_;
     size_t pos_ = 0;
