@@ -86,6 +86,7 @@ struct smafa_db {
     smafa_qset scratch_q;     // query set of smafa_scan_hits / smafa_distances
     smafa_qset scratch_q2;    // the compacted batch of queries the near-hit probe did not finish
     bool two_phase = true;    // near-hit probe before the tightening path (SMAFA_TWO_PHASE=0 disables)
+    uint32_t count_first_k = 3;  // smallest k whose loose-bound scans count first and append second (SMAFA_COUNT_FIRST_K)
     // rows of a smafa_scan_hits call that ended in SMAFA_ERR_CAPACITY, kept for the caller's "grow and retry":
     // the retry with the same arguments against the same store is answered without scanning again
     std::vector<smafa_hit> retry_rows;
@@ -335,7 +336,7 @@ static uint32_t choose_query_block(const smafa_db *db, uint32_t n_wg_tiles, uint
 // one kernel launch: queries [q_begin, q_end) x wave tiles [tile_begin, tile_end)
 static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t tile_begin,
                         uint32_t tile_end, uint32_t k_tight, uint32_t thr0, smafa_hit *d_shards, uint64_t shard_cap,
-                        unsigned long long *d_shard_counts) {
+                        unsigned long long *d_shard_counts, bool per_query_bounds = false) {
     ScanArgs a;
     const bool specialised = db->W <= 4;  // else scan_wide_kernel / scan_generic_kernel
     const bool wide = use_wide(db, thr0);
@@ -348,7 +349,8 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     a.q_begin = q_begin;
     a.q_end = q_end;
     a.qb_size = choose_query_block(db, a.n_wg_tiles, q_end - q_begin);
-    a.thr = k_tight ? qs->thr.as<uint32_t>() : nullptr;  // fixed bound: no per-query array, no fill launch
+    // fixed common bound: no per-query array, no fill launch; per_query_bounds: fixed bounds read from thr
+    a.thr = (k_tight || per_query_bounds) ? qs->thr.as<uint32_t>() : nullptr;
     a.thr0 = thr0;
     a.cnt = qs->cnt.as<uint32_t>();
     a.cnt_stride = db->L + 1;
@@ -391,7 +393,10 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     // when the bound starts loose — of which the gather keeps the ones within the final bound: the scratch block is
     // sized for the appended volume, the caller's buffer only has to hold what is kept.
     uint64_t scratch_rows = 2 * cap;
-    if (k_tight) scratch_rows = std::max<uint64_t>(scratch_rows, std::min<uint64_t>((uint64_t)nq * 128u, 1ull << 27));
+    const uint32_t thr0_ = std::min<uint32_t>(max_div, db->L);
+    // (k >= 2 with a loose bound counts first and appends only the final rows: k per query plus ties)
+    const uint64_t per_query = (k_tight >= db->count_first_k && !prefilter_prunes(db, thr0_)) ? (uint64_t)k_tight + 64u : 128u;
+    if (k_tight) scratch_rows = std::max<uint64_t>(scratch_rows, std::min<uint64_t>((uint64_t)nq * per_query, 1ull << 27));
     const uint64_t shard_cap = (scratch_rows + kShards - 1) / kShards + 256;
     int src = db->shard_rows.ensure(shard_cap * kShards * sizeof(smafa_hit));
     if (!src) src = db->shard_counts.ensure((size_t)kShards * kCountStride * sizeof(unsigned long long));
@@ -424,12 +429,23 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
         const uint32_t seed_tiles = std::min<uint32_t>(k_tight == 1 ? kWgWaves : 1, n_tiles);
         if (!rc) rc = launch_tiles(db, qs, q_begin, q_end, 0, seed_tiles, k_tight, thr0, nullptr, 0, d_shard_counts);
         if (!rc) rc = zero_cnt();  // the seed's subjects are counted again below
+        // k >= 2 with a bound the prefilter cannot use: a query appends every pair within its running k-th bound,
+        // thousands of rows for k = 50 against unrelated subjects.  Two passes instead: the first only counts
+        // (cnt[q][dist]) and tightens, which yields the EXACT k-th distance of every query
+        // (kth_from_counts_kernel); the second appends with those bounds fixed — exactly the rows that are kept.
+        const bool count_first = k_tight >= db->count_first_k && !prefilter_prunes(db, thr0);
         uint32_t begin = 0, len = kWgWaves;
         while (!rc && begin < n_tiles) {
             const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)begin + len, n_tiles);
-            rc = launch_tiles(db, qs, q_begin, q_end, begin, end, k_tight, thr0, d_shards, shard_cap, d_shard_counts);
+            rc = launch_tiles(db, qs, q_begin, q_end, begin, end, k_tight, thr0, count_first ? nullptr : d_shards,
+                              count_first ? 0 : shard_cap, d_shard_counts);
             begin = end;
             len = len > (1u << 28) ? len : len * 8;
+        }
+        if (!rc && count_first) {
+            hipLaunchKernelGGL(kth_from_counts_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream,
+                               qs->cnt.as<uint32_t>(), (uint32_t)cnt_stride, k_tight, qs->thr.as<uint32_t>(), q_begin, nq);
+            rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, thr0, d_shards, shard_cap, d_shard_counts, true);
         }
     }
     if (rc) return rc;
@@ -532,6 +548,14 @@ static int collect_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_
         } else {
             if (!k_tight) break;
             k = k_tight;
+            // counting first, the scan returns k rows per query plus ties: make room for them up front (up to 64M rows)
+            if (k >= db->count_first_k && !prefilter_prunes(db, std::min<uint32_t>(max_div, db->L))) {
+                const uint64_t want = std::min<uint64_t>((uint64_t)(q_end - q_begin) * ((uint64_t)k + 64u), 1ull << 26);
+                if (db->hits_cap() < want) {
+                    int erc = db->hits.ensure(want * sizeof(smafa_hit));
+                    if (erc) return erc;
+                }
+            }
         }
         int rc = scan_range(db, qs, q_begin, q_end, max_div, k, db->hits.as<smafa_hit>(), db->hits_cap(),
                             db->count.as<unsigned long long>());
@@ -707,6 +731,7 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     }
     if (const char *lv = getenv("SMAFA_LAZY")) db->lazy = atoi(lv) != 0;
     if (const char *pv2 = getenv("SMAFA_TWO_PHASE")) db->two_phase = atoi(pv2) != 0;
+    if (const char *cv = getenv("SMAFA_COUNT_FIRST_K")) db->count_first_k = (uint32_t)std::max(2, atoi(cv));
     if (const char *ov = getenv("SMAFA_WIDE_ONE")) db->wide_one = atoi(ov) != 0;
     if (const char *wv = getenv("SMAFA_WIDE_FROM")) db->wide_from = (uint32_t)std::max(3, atoi(wv));
     hipDeviceProp_t prop;

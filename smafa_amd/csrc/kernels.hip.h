@@ -1190,6 +1190,26 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const smafa_hit *shar
     }
 }
 
+// After a counting pass of the k >= 2 modes: every pair within its query's bound was counted in cnt[q][dist], and the
+// bound never dropped below the k-th smallest distance, so the counts up to that distance are complete.  The exact
+// k-th distance is the first d whose cumulative count reaches k (fewer than k pairs in range: the bound stays).
+__global__ void kth_from_counts_kernel(const uint32_t *cnt, uint32_t cnt_stride, uint32_t k, uint32_t *thr,
+                                       uint32_t q_begin, uint32_t nq) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const uint32_t q = q_begin + i;
+    const uint32_t *c = cnt + (size_t)q * cnt_stride;
+    const uint32_t bound = thr[q];
+    uint32_t seen = 0;
+    for (uint32_t d = 0; d <= bound && d < cnt_stride; d++) {
+        seen += c[d];
+        if (seen >= k) {
+            thr[q] = d;
+            return;
+        }
+    }
+}
+
 __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
