@@ -24,7 +24,7 @@ oracle.build()
 t_end, rounds, scans = time.time() + budget, 0, 0
 SWITCHES = {"SMAFA_FILTER": ["1", "1", "1", "0"], "SMAFA_LAZY": ["1", "1", "0"], "SMAFA_TILES": ["", "1", "2", "4"],
             "SMAFA_NT_PLANES": ["", "", "3"], "SMAFA_WIDE_FROM": ["5", "5", "3"], "SMAFA_WIDE_ONE": ["1", "1", "0"],
-            "SMAFA_TWO_PHASE": ["1", "1", "0"]}
+            "SMAFA_TWO_PHASE": ["1", "1", "0"], "SMAFA_COUNT_FIRST_K": ["3", "3", "2", "1000000"]}
 print("soak seed", seed0, flush=True)
 while time.time() < t_end:
     rng = np.random.default_rng(seed0 + rounds)
