@@ -157,6 +157,11 @@ int smafa_select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries
                       const uint8_t *subject_codes, uint32_t seq_len, uint32_t max_div, uint32_t max_num_hits,
                       uint32_t limit_per_sequence, smafa_hit *rows, uint64_t cap, uint64_t *n_rows);
 
+/* Print rows the way query does (src/lib.rs:292,310): "{query_offset + query}\t{subject}\t{dist}\t{subject string}\n"
+ * per row, to out_fd.  For hosts that select rows themselves (the multi-GPU driver on rank 0). */
+int smafa_write_rows(const smafa_hit *rows, uint64_t n_rows, const uint8_t *subject_codes, uint64_t n_subjects,
+                     uint32_t seq_len, int alphabet, uint32_t query_offset, int out_fd);
+
 /* ------------------------------------------------------------------ DB file */
 /* Serialise / parse the reference's v2 DB file (postcard wire format of WindowSet,
  * src/lib.rs:54-60,161-162,208-218).  NT only.  smafa_dbfile_write: codes -> file bytes identical to

@@ -214,6 +214,14 @@ def write_db(path: str, codes: np.ndarray, alphabet: int = ALPHABET_NT) -> None:
     check(lib().smafa_dbfile_write(os.fsencode(path), alphabet, c.ctypes.data, c.shape[0], c.shape[1]))
 
 
+def write_rows(rows: np.ndarray, subject_codes: np.ndarray, alphabet: int, out_fd: int = 1, query_offset: int = 0) -> None:
+    """TSV rows of `query` (src/lib.rs:292,310) for an ordered row list, written to out_fd."""
+    rows = np.ascontiguousarray(rows, dtype=HIT_DTYPE)
+    subject_codes = np.ascontiguousarray(subject_codes, dtype=np.uint8)
+    n, L = subject_codes.shape
+    check(lib().smafa_write_rows(rows.ctypes.data, len(rows), subject_codes.ctypes.data, n, L, alphabet, query_offset, out_fd))
+
+
 # ------------------------------------------------------------------ the crate's pub fns
 def makedb(subject_fasta: str, db_path: str, alphabet: int = ALPHABET_NT) -> None:
     """makedb(subject_fasta, db_path) — src/lib.rs:137-165."""

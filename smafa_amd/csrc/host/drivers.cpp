@@ -587,6 +587,34 @@ int smafa_cluster_sharded(const char *input_fasta, uint32_t max_divergence, int 
     return cluster_run(input_fasta, max_divergence, out_fd, device, alphabet, rank, world, allgather, ctx);
 }
 
+// ---------------------------------------------------------------------------------- write_rows
+int smafa_write_rows(const smafa_hit *rows, uint64_t n_rows, const uint8_t *subject_codes, uint64_t n_subjects,
+                     uint32_t seq_len, int alphabet, uint32_t query_offset, int out_fd) {
+    if ((!rows && n_rows) || (!subject_codes && n_rows)) return set_error(SMAFA_ERR_INVALID, "smafa_write_rows: NULL argument");
+    if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
+        return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
+    std::string text;
+    text.reserve(1u << 20);
+    for (uint64_t i = 0; i < n_rows; i++) {
+        const smafa_hit &h = rows[i];
+        if (h.subject >= n_subjects) return set_error(SMAFA_ERR_INVALID, "row %llu names subject %u of %llu", (unsigned long long)i, h.subject, (unsigned long long)n_subjects);
+        append_u32(text, query_offset + h.query);  // src/lib.rs:292,310
+        text.push_back('\t');
+        append_u32(text, h.subject);
+        text.push_back('\t');
+        append_u32(text, h.dist);
+        text.push_back('\t');
+        append_decoded(text, alphabet, subject_codes + (size_t)h.subject * seq_len, seq_len);
+        text.push_back('\n');
+        if (text.size() > (1u << 20)) {
+            int rc = write_all(out_fd, text.data(), text.size());
+            if (rc) return rc;
+            text.clear();
+        }
+    }
+    return write_all(out_fd, text.data(), text.size());
+}
+
 // -------------------------------------------------------------------------------------- count
 int smafa_count(const char *const *paths, uint64_t n_paths, int out_fd) {
     std::string text = "[";

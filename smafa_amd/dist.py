@@ -157,12 +157,7 @@ def query_sharded(db_path: str, query_fasta: str, max_divergence: Optional[int] 
     rows["query"] += lo  # global query numbers
     all_rows = gather_rows(rows, dist, device)
     if rank == 0:
-        letters = np.array([ord(api.decode(np.array([c], dtype=np.uint8), alphabet)) for c in range(28 if alphabet else 5)],
-                           dtype=np.uint8)
-        chunks = []
-        for r in all_rows:
-            chunks.append(b"%d\t%d\t%d\t" % (r["query"], r["subject"], r["dist"]) + letters[subj[r["subject"]]].tobytes() + b"\n")
-        os.write(out_fd, b"".join(chunks)) if chunks else None
+        api.write_rows(all_rows, subj, alphabet, out_fd)
 
 
 def _main(argv) -> int:
