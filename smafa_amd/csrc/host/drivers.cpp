@@ -70,6 +70,46 @@ void append_decoded(std::string &s, int alphabet, const uint8_t *codes, uint32_t
     for (uint32_t i = 0; i < L; i++) s[base + i] = letter_of(alphabet, codes[i]);
 }
 
+// "{query}\t{subject}\t{distance}\t{subject string}\n" per row (src/lib.rs:292,310), written to fd in order.  Big row
+// lists are formatted by several threads, each into its own buffer over a contiguous slice of the rows.
+int write_rows_text(const smafa_hit *rows, size_t n, const uint8_t *codes, uint32_t L, int alphabet, uint32_t q_base,
+                    int fd) {
+    auto format = [&](size_t lo, size_t hi, std::string &text) {
+        text.clear();
+        text.reserve((hi - lo) * ((size_t)L + 24));
+        for (size_t i = lo; i < hi; i++) {
+            const smafa_hit &h = rows[i];
+            append_u32(text, q_base + h.query);
+            text.push_back('\t');
+            append_u32(text, h.subject);
+            text.push_back('\t');
+            append_u32(text, h.dist);
+            text.push_back('\t');
+            append_decoded(text, alphabet, codes + (size_t)h.subject * L, L);
+            text.push_back('\n');
+        }
+    };
+    const size_t block = 1u << 18;  // rows per write
+    const unsigned T = n >= (1u << 16) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    std::vector<std::string> parts(T);
+    for (size_t b0 = 0; b0 < n; b0 += block * T) {
+        const size_t b1 = std::min(n, b0 + block * T), span = b1 - b0;
+        if (T == 1) {
+            format(b0, b1, parts[0]);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < T; t++)
+                pool.emplace_back([&, t] { format(b0 + span * t / T, b0 + span * (t + 1) / T, parts[t]); });
+            for (auto &th : pool) th.join();
+        }
+        for (unsigned t = 0; t < T; t++) {
+            int rc = write_all(fd, parts[t].data(), parts[t].size());
+            if (rc) return rc;
+        }
+    }
+    return SMAFA_OK;
+}
+
 struct DbGuard {
     smafa_db *db = nullptr;
     ~DbGuard() { smafa_db_destroy(db); }
@@ -248,7 +288,6 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
 
     std::vector<uint8_t> qcodes;
     std::vector<smafa_hit> hits, rows;
-    std::string text;
     uint32_t query_number = 0;  // src/lib.rs:231
     uint64_t in_chunk = 0;
     int pending = SMAFA_OK;  // error to report after the rows already due have been printed
@@ -268,21 +307,10 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
                             limit_per_sequence, rows);
         if (r) return r;
         t_select += now_seconds() - t0;
-        text.clear();
         const uint32_t q_base = query_number - (uint32_t)in_chunk;
-        for (const smafa_hit &h : rows) {
-            append_u32(text, q_base + h.query);
-            text.push_back('\t');
-            append_u32(text, h.subject);
-            text.push_back('\t');
-            append_u32(text, h.dist);
-            text.push_back('\t');
-            append_decoded(text, alphabet, codes + (size_t)h.subject * L, L);
-            text.push_back('\n');
-        }
         in_chunk = 0;
         qcodes.clear();
-        return write_all(out_fd, text.data(), text.size());
+        return write_rows_text(rows.data(), rows.size(), codes, L, alphabet, q_base, out_fd);
     };
 
     FastxRecord rec;
@@ -593,26 +621,11 @@ int smafa_write_rows(const smafa_hit *rows, uint64_t n_rows, const uint8_t *subj
     if ((!rows && n_rows) || (!subject_codes && n_rows)) return set_error(SMAFA_ERR_INVALID, "smafa_write_rows: NULL argument");
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
-    std::string text;
-    text.reserve(1u << 20);
-    for (uint64_t i = 0; i < n_rows; i++) {
-        const smafa_hit &h = rows[i];
-        if (h.subject >= n_subjects) return set_error(SMAFA_ERR_INVALID, "row %llu names subject %u of %llu", (unsigned long long)i, h.subject, (unsigned long long)n_subjects);
-        append_u32(text, query_offset + h.query);  // src/lib.rs:292,310
-        text.push_back('\t');
-        append_u32(text, h.subject);
-        text.push_back('\t');
-        append_u32(text, h.dist);
-        text.push_back('\t');
-        append_decoded(text, alphabet, subject_codes + (size_t)h.subject * seq_len, seq_len);
-        text.push_back('\n');
-        if (text.size() > (1u << 20)) {
-            int rc = write_all(out_fd, text.data(), text.size());
-            if (rc) return rc;
-            text.clear();
-        }
-    }
-    return write_all(out_fd, text.data(), text.size());
+    for (uint64_t i = 0; i < n_rows; i++)
+        if (rows[i].subject >= n_subjects)
+            return set_error(SMAFA_ERR_INVALID, "row %llu names subject %u of %llu", (unsigned long long)i, rows[i].subject,
+                             (unsigned long long)n_subjects);
+    return write_rows_text(rows, n_rows, subject_codes, seq_len, alphabet, query_offset, out_fd);
 }
 
 // -------------------------------------------------------------------------------------- count
