@@ -293,49 +293,86 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
     int pending = SMAFA_OK;  // error to report after the rows already due have been printed
     std::string pending_msg;
 
-    auto flush = [&]() -> int {
-        if (in_chunk == 0) return SMAFA_OK;
+    // scan + select + print `count` queries whose code rows start at qptr; query_number already counts them
+    auto run_chunk = [&](const uint8_t *qptr, uint64_t count) -> int {
+        if (count == 0) return SMAFA_OK;
         hits.clear();
         double t0 = now_seconds();
         if (n > 0) {
-            int r = scan_to_host(guard.db, qcodes.data(), in_chunk, max_divergence, dev_k, hits);
+            int r = scan_to_host(guard.db, qptr, count, max_divergence, dev_k, hits);
             if (r) return r;
         }
         t_scan += now_seconds() - t0;
         t0 = now_seconds();
-        int r = select_rows(hits.data(), hits.size(), in_chunk, n, codes, L, max_divergence, max_num_hits,
+        int r = select_rows(hits.data(), hits.size(), count, n, codes, L, max_divergence, max_num_hits,
                             limit_per_sequence, rows);
         if (r) return r;
         t_select += now_seconds() - t0;
-        const uint32_t q_base = query_number - (uint32_t)in_chunk;
+        return write_rows_text(rows.data(), rows.size(), codes, L, alphabet, query_number - (uint32_t)count, out_fd);
+    };
+    auto flush = [&]() -> int {
+        int r = run_chunk(qcodes.data(), in_chunk);
         in_chunk = 0;
         qcodes.clear();
-        return write_rows_text(rows.data(), rows.size(), codes, L, alphabet, q_base, out_fd);
+        return r;
+    };
+    auto length_panic = [&](size_t len) {  // src/lib.rs:72-79
+        char msg[160];
+        snprintf(msg, sizeof msg, "Cannot compute distances between seq of length %zu and windows of lengths %u", len, L);
+        pending = SMAFA_ERR_PANIC;
+        pending_msg = msg;
     };
 
-    FastxRecord rec;
-    while ((rc = reader.next(rec)) == 1) {
-        int erc = encode_record(alphabet, rec, qcodes);  // src/lib.rs:235
-        if (erc) {
-            pending = erc;
-            pending_msg = smafa_last_error();
-            break;
-        }
-        if (n > 0 && rec.seq_len != L) {  // src/lib.rs:72-79 (only checked when the store has a length)
-            qcodes.resize(qcodes.size() - rec.seq_len);
+    if (n > 0 && !reader.is_fastq() && reader.size() >= (32u << 20) && reader.size() <= (4ull << 30)) {
+        // big plain-FASTA query files: every record parsed and encoded up front by several threads (the loader stops
+        // at the first offending record in file order, like the loop below), then scanned chunk by chunk
+        BulkRecords recs;
+        rc = load_records_bulk(query_fasta, alphabet, false, recs);
+        if (rc) return rc;
+        uint64_t usable = recs.n;
+        if (recs.n > 0 && recs.L != L) {  // the first query already fails the length check: nothing is printed
+            usable = 0;
+            length_panic(recs.L);
+        } else if (recs.err_kind == 1) {  // src/lib.rs:38-41
             pending = SMAFA_ERR_PANIC;
-            char msg[160];
-            snprintf(msg, sizeof msg, "Cannot compute distances between seq of length %zu and windows of lengths %u",
-                     rec.seq_len, L);
-            pending_msg = msg;
-            break;
+            pending_msg = recs.err_msg;
+        } else if (recs.err_kind == 2) {
+            length_panic(recs.err_len);
+        } else if (recs.err_kind == 3) {
+            length_panic(0);
+        } else if (recs.err_kind == 4) {
+            pending = SMAFA_ERR_FORMAT;
+            pending_msg = recs.err_msg;
         }
-        if (n == 0) qcodes.resize(qcodes.size() - rec.seq_len);  // nothing to compare with; selection will panic
-        in_chunk++;
-        query_number++;
-        if (in_chunk >= chunk_queries) {
-            int frc = flush();
+        if (usable > 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many queries");
+        for (uint64_t off = 0; off < usable; off += chunk_queries) {
+            const uint64_t count = std::min<uint64_t>(chunk_queries, usable - off);
+            query_number += (uint32_t)count;
+            int frc = run_chunk(recs.codes.data() + (size_t)off * L, count);
             if (frc) return frc;
+        }
+        rc = 0;
+    } else {
+        FastxRecord rec;
+        while ((rc = reader.next(rec)) == 1) {
+            int erc = encode_record(alphabet, rec, qcodes);  // src/lib.rs:235
+            if (erc) {
+                pending = erc;
+                pending_msg = smafa_last_error();
+                break;
+            }
+            if (n > 0 && rec.seq_len != L) {  // only checked when the store has a length
+                qcodes.resize(qcodes.size() - rec.seq_len);
+                length_panic(rec.seq_len);
+                break;
+            }
+            if (n == 0) qcodes.resize(qcodes.size() - rec.seq_len);  // nothing to compare with; selection will panic
+            in_chunk++;
+            query_number++;
+            if (in_chunk >= chunk_queries) {
+                int frc = flush();
+                if (frc) return frc;
+            }
         }
     }
     if (rc < 0 && pending == SMAFA_OK) {

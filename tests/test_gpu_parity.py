@@ -651,3 +651,40 @@ def test_randomized_api_sweep_vs_oracle_aa():
         want = full if k is None else expected_with_k(full, k)
         assert got.tobytes() == want.tobytes(), (trial, L, n, nq, n_letters, D, k)
         store.close()
+
+
+def test_big_query_file_takes_the_threaded_loader_and_matches_oracle(tmp_path):
+    """query files of 32 MB and more are parsed and encoded by several threads before the scans: same rows, and the
+    same failure at the same record (bad byte, wrong length, wrong first length) after the same rows"""
+    rng = np.random.default_rng(99)
+    L, n, nq = 60, 400, 560_000  # 560k x (60 + header) bytes = 38 MB of FASTA
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    s = letters[rng.integers(0, 4, size=(n, L))]
+    q = s[rng.integers(0, n, size=nq)].copy()
+    sub = rng.random(size=q.shape) < 0.03
+    q[sub] = letters[rng.integers(0, 4, size=int(sub.sum()))]
+    sf, db = str(tmp_path / "s.fna"), str(tmp_path / "db")
+    oracle.write_fasta(sf, [bytes(r) for r in s])
+    assert cli("makedb", "-i", sf, "-d", db).returncode == 0
+
+    def write_queries(path, rows, patch=None):
+        body = bytearray()
+        for i, r in enumerate(rows):
+            body += b">q%d\n" % i
+            body += (patch[i] if patch and i in patch else bytes(r)) + b"\n"
+        open(path, "wb").write(body)
+        assert len(body) >= 32 << 20
+
+    qf = str(tmp_path / "q.fna")
+    write_queries(qf, q)
+    for flags in (["--max-divergence", "2"], []):
+        got, want = both_cli("query", "-d", db, "-q", qf, *flags)
+        assert got.returncode == want.returncode == 0 and got.stdout == want.stdout and len(got.stdout) > 1_000_000, flags
+    # a byte outside the alphabet deep in the file; a record of another length; a first record of another length
+    for patch in ({401_234: bytes(q[401_234][:30]) + b"E" + bytes(q[401_234][31:])}, {333_333: bytes(q[333_333][:59])},
+                  {0: bytes(q[0]) + b"A", 7: b"ACGTE"}):
+        write_queries(qf, q, patch)
+        got, want = both_cli("query", "-d", db, "-q", qf, "--max-divergence", "1")
+        assert got.returncode == want.returncode == 101, patch.keys()
+        assert got.stdout == want.stdout
+        assert got.stderr.strip().splitlines()[-1] == want.stderr.strip().splitlines()[-1]
