@@ -105,6 +105,12 @@ __device__ __forceinline__ uint32_t or3(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE);
 }
 
+// number of set bits of a wave mask in the lanes below the calling lane (v_mbcnt_lo/hi): a lane's rank among the
+// lanes that append together
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 __device__ __forceinline__ uint32_t ld_relaxed(const uint32_t *p) {
     // agent-scope relaxed load: bypasses the non-coherent caches, so a bound lowered by a workgroup on
     // another XCD is seen (a stale, higher value would still be correct — see emit()).
@@ -118,8 +124,8 @@ __device__ __forceinline__ uint32_t ld_relaxed(const uint32_t *p) {
 __device__ __forceinline__ void emit(const ScanArgs &a, uint32_t q, uint32_t subject, uint32_t dist) {
     if (a.hits) {
         // One atomic per wave, not per row: the lanes that got here together (a wave works on one query at a
-        // time, so they all append for the same query) take consecutive slots.  On dense stores most lanes
-        // of a wave have a row, and 64 same-address atomics in a row were the bottleneck of the scan.
+        // time, so they all append for the same query) take consecutive slots.  (What limited dense scans was
+        // not the number of atomics but counters sharing cache lines — see kCountStride.)
         const unsigned long long together = __ballot(1);  // the active lanes
         const uint32_t lane = __lane_id();
         const int leader = __builtin_ctzll(together);
@@ -128,7 +134,7 @@ __device__ __forceinline__ void emit(const ScanArgs &a, uint32_t q, uint32_t sub
         if ((int)lane == leader) base = atomicAdd(a.count + (size_t)shard * kCountStride, (unsigned long long)__builtin_popcountll(together));
         base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), leader, 64) << 32) |
                (uint32_t)__shfl((int)(base & 0xffffffffull), leader, 64);
-        const unsigned long long slot = base + (unsigned long long)__builtin_popcountll(together & ((1ull << lane) - 1ull));
+        const unsigned long long slot = base + lanes_below(together);  // v_mbcnt: set bits of `together` below this lane
         if (slot < a.shard_cap) {
             smafa_hit h;
             h.query = q;
@@ -1185,7 +1191,7 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const smafa_hit *shar
         if (lane == 0) first = atomicAdd(out_count, (unsigned long long)__builtin_popcountll(mask));
         first = ((unsigned long long)(uint32_t)__shfl((int)(first >> 32), 0, 64) << 32) |
                 (uint32_t)__shfl((int)(first & 0xffffffffull), 0, 64);
-        const unsigned long long slot = first + (unsigned long long)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        const unsigned long long slot = first + lanes_below(mask);
         if (keep && slot < cap) out[slot] = h;
     }
 }
