@@ -271,17 +271,18 @@ static void launch_wide_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
     // resident filter words per subject: 1 = one-word store (plus word 0 of a second plane), else 3 (a fourth
     // pushes the kernel past 128 VGPRs: measured spills, and one wave per SIMD less)
     const uint32_t fw = db->W == 1 ? 1u : 3u;
-#define SMAFA_WIDE(FW_)                                                                                              \
-    if (fw == FW_) {                                                                                                 \
-        if (seed)                                                                                                    \
-            hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, true, FW_>), dim3(grid), dim3(256), 0, db->stream, planes,  \
-                               d_qrec, a, db->W);                                                                    \
-        else                                                                                                         \
-            hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, false, FW_>), dim3(grid), dim3(256), 0, db->stream, planes, \
-                               d_qrec, a, db->W);                                                                    \
-        return;                                                                                                      \
+    const uint32_t wc = (db->W == 3 || db->W == 4) ? db->W : 0u;  // compile-time word count: register-resident dense walk
+#define SMAFA_WIDE(FW_, WC_)                                                                                     \
+    if (fw == FW_ && wc == WC_) {                                                                               \
+        if (seed)                                                                                               \
+            hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, true, FW_, WC_>), dim3(grid), dim3(256), 0, db->stream, \
+                               planes, d_qrec, a, db->W);                                                       \
+        else                                                                                                    \
+            hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, false, FW_, WC_>), dim3(grid), dim3(256), 0, db->stream, \
+                               planes, d_qrec, a, db->W);                                                       \
+        return;                                                                                                 \
     }
-    SMAFA_WIDE(1) SMAFA_WIDE(3)
+    SMAFA_WIDE(1, 0) SMAFA_WIDE(3, 0) SMAFA_WIDE(3, 3) SMAFA_WIDE(3, 4)
 #undef SMAFA_WIDE
 }
 

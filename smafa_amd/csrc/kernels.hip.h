@@ -677,9 +677,12 @@ constexpr int kWideStage = 768;  // uint4 per LDS buffer
 __host__ __device__ constexpr int wide_group(int ps) { return ps >= 5 ? 4 : ps == 3 ? 6 : 8; }
 __host__ __device__ constexpr bool wide_fits(int planes, int words) { return qrec_stride(planes, words) / 4 <= kWideStage; }
 
-template <int PS, int PQ, bool SEED, int FW>
+template <int PS, int PQ, bool SEED, int FW, int WC>
 __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restrict__ planes,
-                                                           const uint32_t *__restrict__ qrec, ScanArgs a, uint32_t W) {
+                                                           const uint32_t *__restrict__ qrec, ScanArgs a, uint32_t W_arg) {
+    // WC > 0: the word count is a compile-time constant (33..128 columns): record offsets fold to immediates and the
+    // dense walk keeps a tile's planes in registers, like scan_lazy_kernel; WC == 0: any W at run time
+    const uint32_t W = WC > 0 ? (uint32_t)WC : W_arg;
     constexpr int T = kWideTiles;
     constexpr bool ONE = FW == 1;          // one-word store: the second register word is word 0 of another plane
     constexpr int NF = ONE ? 2 : FW;       // register words per subject
@@ -810,6 +813,45 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
     // Streaming a tile from L2 once per query would cost P*W KB per (tile, query); instead a tile's words are
     // loaded once per group of kWideGroup queries and the group's 4 * kWideGroup distances live in registers.
     auto dense_walk = [&](const uint32_t *rec0, uint32_t nqc, uint32_t qc) {
+        if constexpr (WC > 0) {
+            // compile-time W: one pass over the chunk per tile, that tile's planes in registers (the filter words are
+            // dead meanwhile and reloaded afterwards)
+            for (uint32_t t = 0; t < (uint32_t)T; t++) {
+                const uint32_t tile = tile0 + t;
+                if (tile >= a.tile_end) break;
+                const uint4 *src = planes + (size_t)tile * tile_stride + lane;
+                uint4 s[PS * (WC > 0 ? WC : 1)];
+#pragma unroll
+                for (int i = 0; i < PS * WC; i++) s[i] = src[i * 64];
+                const uint32_t *rec = rec0;
+                for (uint32_t i = 0; i < nqc; i++, rec += RS) {
+                    const uint32_t U = ~rec[BS];
+                    uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+                    for (int w = 0; w < WC; w++) {
+                        uint32_t extra = 0;
+#pragma unroll
+                        for (int p = PS; p < PQ; p++) extra |= rec[qslot(PQ, WC, p, w)];
+                        uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
+#pragma unroll
+                        for (int p = 0; p < PS; p++) {
+                            const uint4 v = s[p * WC + w];
+                            const uint32_t qv = rec[qslot(PQ, WC, p, w)];
+                            m0 = or_xor(m0, v.x, qv);
+                            m1 = or_xor(m1, v.y, qv);
+                            m2 = or_xor(m2, v.z, qv);
+                            m3 = or_xor(m3, v.w, qv);
+                        }
+                        d0 += __builtin_popcount(m0);
+                        d1 += __builtin_popcount(m1);
+                        d2 += __builtin_popcount(m2);
+                        d3 += __builtin_popcount(m3);
+                    }
+                    if (__ballot(min(min(d0, d1), min(d2, d3)) <= U) != 0ull) finish(tile, qc + i, U, d0, d1, d2, d3);
+                }
+            }
+            return;
+        }
         for (uint32_t t = 0; t < (uint32_t)T; t++) {
             const uint32_t tile = tile0 + t;
             if (tile >= a.tile_end) break;
