@@ -524,11 +524,19 @@ static int fetch_rows(smafa_db *db, uint64_t count, uint32_t q_begin, uint32_t q
         int rc = sort_rows_on_device(db, count, q_begin, q_end, &sorted);
         if (rc) return rc;
     }
+    const double t0 = now_seconds();
+    HIP_TRY(hipStreamSynchronize(db->stream));
+    const double t1 = now_seconds();
     const size_t old = out.size();
     out.resize(old + count);
+    const double t2 = now_seconds();
     HIP_TRY(hipMemcpyAsync(out.data() + old, db->hits.p, count * sizeof(smafa_hit), hipMemcpyDeviceToHost, db->stream));
     HIP_TRY(hipStreamSynchronize(db->stream));
+    const double t3 = now_seconds();
     if (!sorted) std::sort(out.begin() + old, out.end(), hit_less);  // each range ordered => `out` ordered
+    if (count >= (1u << 20))
+        log_line(2, "%llu rows: scan + device sort %.2f ms, host buffer %.2f ms, copy back %.2f ms", (unsigned long long)count,
+                 (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3);
     return SMAFA_OK;
 }
 
