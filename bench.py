@@ -1,38 +1,45 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the smafa scan engine on MI355X.
 
-Metric (BASELINE.json): query seqs/sec (+ DB residues/sec) vs the HBM roofline, 10M x 60-aa DB, d <= 5.
+Metric (BASELINE.json): query seqs/sec (+ DB residues/sec) vs the roofline, 10M x 60-aa DB, d <= 5.
 A "step" = one pass of the hot path over one batch: every query of the batch (default 10 000 per GPU)
 scanned against the whole resident subject store, qualifying rows appended on the device, and — when
-more than one GPU takes part — the per-rank row lists gathered on rank 0 over RCCL.  The packed subject
-block and the packed query batch are resident in HBM before the timed region starts.
+more than one GPU takes part — the per-rank row lists gathered over RCCL.  The packed subject block and the
+packed query batch are resident in HBM before the timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            # N = 1
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Rank 0 prints ONE JSON line.  Scaling is weak: the DB is replicated, every rank scans its own query
-shard of fixed size.  `roofline` is for the dominant kernel (scan_kernel), timed with HIP events on the
-launch stream; `cpu_baseline` is the oracle's single-thread port of the reference's per-query loop on a
-bounded sample (the only place bench.py touches oracle/, besides the post-run result check).
+With --gpus N > 1 and no torch.distributed environment, this process only spawns
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` (before touching torch or the GPU), relays
+rank 0's JSON line and exits with the child's code; under torch.distributed.run it is one of the N ranks.
+
+Rank 0 prints ONE JSON line.  Scaling is weak: the store is replicated, every rank scans its own query shard
+of fixed size.  `roofline` is for the dominant kernel, timed with HIP events on the launch stream; its binding
+resource is VALU issue (integer xor/popcount), so `frac` = VALU lane-ops/s over the chip's nominal issue peak,
+with the instruction count taken from the committed rocprofv3 counter profile of this same command
+(`tools/collect_pmc.py` -> profiles/r02_pmc.json; `insts_source` says which, and whether it belongs to this
+build).  `cpu_baseline` is the oracle's port of the reference's per-query loop on a bounded sample (the only
+place bench.py touches oracle/, besides the post-run result checks).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz (one wave64 VALU op = 2 cycles)
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -44,14 +51,136 @@ def main() -> None:
     ap.add_argument("--max-div", type=int, default=5)
     ap.add_argument("--n-frac", type=float, default=0.0,
                     help="nt only: each column becomes N with this probability (SURVEY 8d variant B: 0.001, 3-plane store)")
+    ap.add_argument("--store", choices=["uniform", "related"], default="uniform",
+                    help="related: the TIMED workload is the related-families store (default: uniform letters; the related "
+                         "store is then a side leg)")
     ap.add_argument("--query-block", type=int, default=0, help="queries per workgroup pass (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-stream", action="store_true", help="skip the one-query-per-pass leg (clean rocprof stats)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-stream", action="store_true", help="skip the side legs that launch other kernels (clean rocprof stats)")
+    ap.add_argument("--no-related", action="store_true", help="skip the related-store leg")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU time budget per CPU baseline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (tests use gloo)")
     ap.add_argument("--single-device", action="store_true", help="testing only: every rank uses GPU 0")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def self_launch(args) -> int:
+    """--gpus N > 1 from a plain shell: start the N ranks as a child job.  Nothing in this process has touched
+    torch or the GPU, and it never execs: it waits, and passes the child's output and exit code on."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def sorted_rows(rows):
+    """(n, 3) uint32 rows [query, subject, dist] -> ordered by (query, dist, subject), the reference's print order"""
+    import numpy as np
+
+    order = np.lexsort((rows[:, 1], rows[:, 2], rows[:, 0]))
+    return np.ascontiguousarray(rows[order])
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+_B2 = {}  # state the forked B2 workers inherit
+
+
+def _b2_work(idx):
+    import numpy as np
+
+    return _B2["db"].bench_besthit(np.ascontiguousarray(_B2["enc"][idx]), _B2["D"])
+
+
+def cpu_baselines(N, L, D, alphabet_name, subj_codes, q_codes, budget_s):
+    """SURVEY 8(d) / BASELINE.md §2: the reference's per-query loop (src/lib.rs:238 distances, :298 min, :307 equality
+    pass) restated by the oracle and timed on this host, each on a bounded sample.
+      B1   5-bit one-hot u64 x ceil(L/12) per subject (the reference's own arithmetic, src/lib.rs:71-89), ONE thread,
+           gcc -O3 for baseline x86-64 (no POPCNT: what `cargo build --release` gives)
+      B1n  the same, -march=native
+      B2   B1n over min(16, nproc) worker processes (query shards; the reference has no threads: a courtesy baseline)
+      aa   the code-byte port (one byte per column): the only CPU form that can hold amino-acid letters
+    The reference's cost does not depend on the letters (same words per subject), so for the amino-acid metric B1..B2
+    run on a nucleotide store of the same shape (seed 2) — the reference itself rejects amino-acid input."""
+    import multiprocessing as mp
+
+    import numpy as np
+
+    import oracle
+    from smafa_amd import synth
+
+    oracle.build()
+    out = {"cpu_model": cpu_model(), "nproc": os.cpu_count()}
+    NT = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    if alphabet_name == "nt":
+        s_nt, q_nt = subj_codes, q_codes[:512]
+    else:
+        s_nt = synth.subjects(N, L, 0, seed=2)
+        q_nt, _, _ = synth.queries(s_nt, 512, 0, seed=3, max_subs=6)
+    sa, qa = NT[s_nt], NT[q_nt]
+
+    def sample_size(per_q, cap):
+        return int(max(4, min(cap, budget_s / max(per_q, 1e-6))))
+
+    for key, native in (("b1", False), ("b1n", True)):
+        db = oracle.OnehotDB(sa, native=native)
+        enc = db.encode_queries(qa)
+        t = time.perf_counter()
+        db.bench_besthit(enc[:2], D)
+        n_s = sample_size((time.perf_counter() - t) / 2, len(enc))
+        t = time.perf_counter()
+        db.bench_besthit(enc[:n_s], D)
+        dt = time.perf_counter() - t
+        out[key] = {"value": n_s / dt, "unit": "query seqs/s", "cores": 1, "queries": n_s,
+                    "build": "gcc -O3 -march=native" if native else "gcc -O3, baseline x86-64 (no POPCNT)"}
+        if native:
+            workers = min(16, os.cpu_count() or 1)
+            per_q = dt / n_s
+            n_b2 = int(max(workers, min(len(enc), workers * budget_s / per_q)))
+            shards = np.array_split(np.arange(n_b2), workers)
+
+            _B2.update(db=db, enc=enc, D=D)
+            ctx = mp.get_context("fork")  # the store is shared copy-on-write with the workers
+            t = time.perf_counter()
+            with ctx.Pool(workers) as pool:
+                pool.map(_b2_work, shards)
+            dt2 = time.perf_counter() - t
+            _B2.clear()
+            out["b2"] = {"value": n_b2 / dt2, "unit": "query seqs/s", "cores": workers, "queries": n_b2,
+                         "build": "gcc -O3 -march=native, %d worker processes" % workers}
+        db.close()
+    if alphabet_name == "aa":
+        t = time.perf_counter()
+        oracle.bench_besthit_codes(subj_codes, q_codes[:2], D)
+        n_s = sample_size((time.perf_counter() - t) / 2, len(q_codes))
+        t = time.perf_counter()
+        oracle.bench_besthit_codes(subj_codes, q_codes[:n_s], D)
+        dt = time.perf_counter() - t
+        out["aa_code_bytes"] = {"value": n_s / dt, "unit": "query seqs/s", "cores": 1, "queries": n_s,
+                                "build": "gcc -O3, one byte per column, the same store and queries as the GPU"}
+    return out
+
+
+def main() -> int:
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(args)
+
+    import numpy as np
     import torch
 
     import smafa_amd
@@ -61,7 +190,7 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available() or smafa_amd.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the scan engine has no CPU fallback")
     if args.single_device:
@@ -79,10 +208,15 @@ def main() -> None:
     alphabet = smafa_amd.ALPHABET_AA if args.alphabet == "aa" else smafa_amd.ALPHABET_NT
     L, N, Q, D = args.seq_len, args.db_rows, args.queries, args.max_div
     max_subs = 10 if alphabet == smafa_amd.ALPHABET_AA else 6
+    side_legs = rank == 0 and not args.no_stream
 
-    # ---- synthetic workload: identical DB on every rank, disjoint query shards
+    # ---- synthetic workload: identical store on every rank, disjoint query shards
     t_gen = time.time()
-    subj = synth.subjects(N, L, alphabet, seed=1 if alphabet else 2, n_frac=args.n_frac)  # seeds of SURVEY 8d
+    if args.store == "related":
+        subj = synth.related_subjects(N // 100, 100, L, alphabet, seed=7)
+        N = len(subj)
+    else:
+        subj = synth.subjects(N, L, alphabet, seed=1 if alphabet else 2, n_frac=args.n_frac)  # seeds of SURVEY 8d
     all_q, planted_row, planted_subs = synth.queries(subj, Q * world, alphabet, seed=3, max_subs=max_subs)
     q_lo = rank * Q
     my_q = all_q[q_lo:q_lo + Q]
@@ -156,115 +290,187 @@ def main() -> None:
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     kernel_ms_avg = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     plan = store.last_scan_plan()  # which kernel form the timed launches used
+    kernel_name = store.last_scan_kernel()
 
-    # ---- result check (outside the timed region): planted rows present, every row's distance recomputed
+    def launch_rows(the_store, the_qset):
+        """one more launch outside the timed region -> its rows, ordered"""
+        the_store.scan_launch(the_qset, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
+        torch.cuda.synchronize()
+        n = int(d_count.item())
+        r = d_hits[: 3 * min(n, cap)].cpu().numpy().view(np.uint32).reshape(-1, 3)
+        return n, sorted_rows(r)
+
+    # ---- result checks (outside the timed region)
     last = (it[0] - 1) % len(bufs)
     d_hits, d_count = bufs[last][HEAD:], bufs[last][:2].view(torch.int64)
     n_rows = int(d_count.item())
-    rows = d_hits[: 3 * min(n_rows, cap)].cpu().numpy().view(np.uint32).reshape(-1, 3)
-    ok = n_rows <= cap
+    rows = sorted_rows(d_hits[: 3 * min(n_rows, cap)].cpu().numpy().view(np.uint32).reshape(-1, 3))
+    checks = {"rows_fit": n_rows <= cap}
     if world > 1:  # what the gather delivered: this rank's block must be its own buffer, every count within capacity
         g = gathered[last].view(world, HEAD + cap * 3)
-        ok = ok and bool(torch.equal(g[rank], bufs[last]))
-        ok = ok and all(0 <= int(g[r][:2].view(torch.int64).item()) <= cap for r in range(world))
+        checks["gather_block_is_own_buffer"] = bool(torch.equal(g[rank], bufs[last]))
+        checks["gather_counts_in_range"] = all(0 <= int(g[r][:2].view(torch.int64).item()) <= cap for r in range(world))
+    # (1) soundness: every row's distance recomputed from the code bytes
     recomputed = (subj[rows[:, 1]] != my_q[rows[:, 0]]).sum(axis=1)
-    ok = ok and bool((recomputed == rows[:, 2]).all()) and bool((rows[:, 2] <= D).all())
+    checks["distances_recomputed"] = bool((recomputed == rows[:, 2]).all()) and bool((rows[:, 2] <= D).all())
+    # (2) recall of the planted rows
     have = set(zip(rows[:, 0].tolist(), rows[:, 1].tolist()))
-    for qi in range(Q):
-        if planted_subs[q_lo + qi] <= D and (qi, int(planted_row[q_lo + qi])) not in have:
-            ok = False
-            break
+    checks["planted_rows_present"] = all(
+        planted_subs[q_lo + qi] > D or (qi, int(planted_row[q_lo + qi])) in have for qi in range(Q))
+    # (3) the prefilter is an exact early-out: the same launch with it switched off must give the same BYTES
+    store.set_prefilter(False)
+    n_off, rows_off = launch_rows(store, qset)
+    unfiltered_kernel = store.last_scan_kernel()
+    u_ms = []
+    if side_legs:
+        for _ in range(5):
+            store.scan_launch(qset, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
+            u_ms.append(store.last_scan_ms()[0])
+    store.set_prefilter(True)
+    checks["filter_on_off_rows_identical"] = n_off == n_rows and rows_off.tobytes() == rows.tobytes()
+    # (4) an oracle scan of 8 sampled queries against the whole store: complete row lists, bit for bit
+    if rank == 0:
+        import oracle
+
+        oracle.build()
+        pick = np.unique(np.concatenate([np.nonzero(planted_subs[q_lo:q_lo + Q] <= D)[0][:4],
+                                         np.random.default_rng(5).integers(0, Q, size=4)]))[:8]
+        want = oracle.scan_codes(subj, my_q[pick], D)  # ordered (query, dist, subject), query = index into `pick`
+        got = rows[np.isin(rows[:, 0], pick)]
+        remap = {int(q): i for i, q in enumerate(pick)}
+        got = np.array([[remap[int(q)], s, d] for q, s, d in got], dtype=np.uint32).reshape(-1, 3)
+        got = sorted_rows(got)
+        want_a = np.stack([want["query"], want["subject"], want["dist"]], axis=1).astype(np.uint32)
+        checks["oracle_sample_identical"] = got.tobytes() == want_a.tobytes()
+        checks["oracle_sample_queries"] = int(len(pick))
+    ok = all(v for k, v in checks.items() if isinstance(v, bool))
     if world > 1:
         flag = torch.tensor([1 if ok else 0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
 
-    # ---- stream mode: ONE query per pass — the HBM-bound form of the same kernel (north_star's literal
-    #      "broadcast each query against all subjects"); reported beside the batched roofline
+    unfiltered = None
+    if u_ms:
+        u_med = float(np.median(u_ms))
+        unfiltered = {"kernel": unfiltered_kernel, "kernel_ms": u_med, "queries_per_s": Q / (u_med * 1e-3), "rows": n_off,
+                      "note": "the same launch with the prefilter disabled (smafa_set_prefilter 0): all planes, all "
+                              "words, for every pair; rows byte-identical (checks.filter_on_off_rows_identical)"}
+
+    # ---- stream mode: ONE query per pass — the HBM-bound form (north_star's literal "broadcast each query against
+    #      all subjects"); three fractions of the 8 TB/s peak + the box's empirical read ceiling
     stream_info = None
-    if rank == 0 and not args.no_stream:
+    if side_legs:
         one = smafa_amd.QuerySet(store, my_q[:1])
         for _ in range(3):
             store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 50
+        reps = 200
         e0.record(stream)
         for _ in range(reps):
             store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
         e1.record(stream)
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps  # includes the counter-reset launch and launch gaps
-        k_ms = []
+        ms = e0.elapsed_time(e1) / reps  # everything one query costs on the stream: launches, gaps, row bookkeeping
+        k_ms, launches = [], 0
         for _ in range(20):  # kernel-only time: HIP events recorded by the library right around the scan kernel
             store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
-            k_ms.append(store.last_scan_ms()[0])
+            m, launches = store.last_scan_ms()
+            k_ms.append(m)
         k_med = float(np.median(k_ms))
         splan = store.last_scan_plan()
         # bytes one pass streams: the whole block, or only the prefilter's plane when that is all that is resident
         sb = info.words_per_plane * 4 if splan["filter_plane_resident"] else info.bytes_per_subject
         streamed = info.hbm_bytes * sb / info.bytes_per_subject
+        alg = N * L * (8 if args.alphabet == "aa" else int(info.planes)) / 8
+        ceiling = smafa_amd.hbm_read_probe(local_rank, 8 << 30)
         stream_info = {
-            "ms_per_query": ms,
+            "kernel": store.last_scan_kernel(),
+            "ms_per_query_wall": ms,
             "kernel_ms_median": k_med,
+            "launches_per_query": launches,
             "streamed_bytes_per_subject": int(sb),
+            "frac_kernel_streamed": streamed / k_med / 1e6 / HBM_PEAK_GBS,
+            "frac_wall_streamed": streamed / ms / 1e6 / HBM_PEAK_GBS,
+            "algorithmic_x_of_peak": alg / k_med / 1e6 / HBM_PEAK_GBS,
             "kernel_streamed_GBs": streamed / k_med / 1e6,
-            "kernel_frac_of_peak": streamed / k_med / 1e6 / HBM_PEAK_GBS,
-            "kernel_algorithmic_GBs": N * L * (8 if args.alphabet == "aa" else int(info.planes)) / 8 / k_med / 1e6,
+            "empirical_read_ceiling_GBs": ceiling,
+            "empirical_read_ceiling_frac_of_peak": ceiling / HBM_PEAK_GBS,
             "plan": splan,
-            "note": "one query per DB pass; streamed = bit-plane bytes the kernel actually reads per subject (the "
-                    "prefilter's plane only when the other planes are fetched on demand); algorithmic = %g B/subject"
-                    % (L * (8 if args.alphabet == "aa" else int(info.planes)) / 8),
+            "note": "one query per store pass. frac_kernel_streamed / frac_wall_streamed = bytes the kernel actually "
+                    "reads per pass (the prefilter's bit-plane only when the other planes are fetched on demand) over "
+                    "kernel time / wall time per query, as a fraction of 8 TB/s; algorithmic_x_of_peak = %g B/subject "
+                    "over kernel time (a reuse figure, not an efficiency); empirical ceiling = smafa_hbm_read_probe, a "
+                    "trivial sum over 8 GiB on this box" % (alg / N),
         }
         one.close()
 
-    # ---- the same launch with the prefilter off: every pair gets the full comparison (results identical)
-    unfiltered = None
-    if rank == 0 and not args.no_stream:
-        store.set_prefilter(False)
-        store.scan_launch(qset, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
-        torch.cuda.synchronize()
-        u_ms = []
-        for _ in range(5):
-            store.scan_launch(qset, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
-            u_ms.append(store.last_scan_ms()[0])
-        store.set_prefilter(True)
-        u_med = float(np.median(u_ms))
-        unfiltered = {"kernel_ms": u_med, "queries_per_s": Q / (u_med * 1e-3), "rows": int(d_count.item()),
-                      "note": "SAME kernel, prefilter disabled (smafa_set_prefilter 0): all planes, all words, "
-                              "for every pair"}
-
     # ---- host-buffer API (PCIe-inclusive): queries uploaded + packed, rows copied back and ordered on the host
     host_api = None
-    if rank == 0 and world == 1 and not args.no_stream:
+    if side_legs and world == 1:
         store.scan(my_q[:64], max_divergence=D)
         reps = 3
         tq = time.perf_counter()
         for _ in range(reps):
             rows_h = store.scan(my_q, max_divergence=D)
         dt = (time.perf_counter() - tq) / reps
+        rh = np.stack([rows_h["query"], rows_h["subject"], rows_h["dist"]], axis=1).astype(np.uint32)
         host_api = {"queries_per_s": Q / dt, "ms_per_batch": dt * 1e3, "rows": int(len(rows_h)),
+                    "rows_identical_to_device_launch": rh.tobytes() == rows.tobytes(),
                     "note": "smafa_scan_hits: host code bytes in, ordered rows out (upload, pack, scan, copy back, sort)"}
 
-    # ---- CPU baseline: the oracle's port of the reference's per-query loop, one thread, bounded sample
+    # ---- related store: 100 members per family at 10-25 % divergence from the family root — the regime smafa is used
+    #      in (homologous windows), where a lower-bound prefilter has less to reject than on uniform letters
+    related = None
+    if side_legs and world == 1 and not args.no_related and args.store == "uniform":
+        tg = time.time()
+        r_subj = synth.related_subjects(max(N // 100, 1), 100, L, alphabet, seed=7)
+        r_q, r_row, r_subs = synth.queries(r_subj, Q, alphabet, seed=8, max_subs=max_subs)
+        tg = time.time() - tg
+        r_store = smafa_amd.SubjectStore(L, alphabet, local_rank)
+        r_store.push(r_subj)
+        r_store.set_stream(stream.cuda_stream)
+        r_qset = smafa_amd.QuerySet(r_store, r_q)
+        n_r, rows_r = launch_rows(r_store, r_qset)
+        r_ms = []
+        for _ in range(10):
+            r_store.scan_launch(r_qset, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
+            r_ms.append(r_store.last_scan_ms()[0])
+        r_kernel = r_store.last_scan_kernel()
+        r_store.set_prefilter(False)
+        n_r_off, rows_r_off = launch_rows(r_store, r_qset)
+        r_store.set_prefilter(True)
+        rec = (r_subj[rows_r[:, 1]] != r_q[rows_r[:, 0]]).sum(axis=1)
+        have_r = set(zip(rows_r[:, 0].tolist(), rows_r[:, 1].tolist()))
+        r_ok = (n_r <= cap and n_r == n_r_off and rows_r.tobytes() == rows_r_off.tobytes()
+                and bool((rec == rows_r[:, 2]).all())
+                and all(r_subs[qi] > D or (qi, int(r_row[qi])) in have_r for qi in range(Q)))
+        r_med = float(np.median(r_ms))
+        related = {"kernel": r_kernel, "kernel_ms": r_med, "queries_per_s": Q / (r_med * 1e-3), "rows": n_r,
+                   "slowdown_vs_uniform": r_med / kernel_ms_avg, "verified": r_ok,
+                   "workload": "%d families x 100 members, each member 10-25 %% of its columns substituted against the "
+                               "family root (rows shuffled, seed 7); %d queries = store members with 0..%d substitutions "
+                               "(seed 8); max-divergence %d" % (len(r_subj) // 100, Q, max_subs, D),
+                   "generate_s": tg}
+        ok = ok and r_ok
+        r_qset.close()
+        r_store.close()
+        del r_subj
+
+    # ---- CPU baselines: the oracle's port of the reference's per-query loop, bounded samples
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle
-
-        oracle.build()
-        tq = time.perf_counter()
-        oracle.bench_besthit_codes(subj, my_q[:2], D)
-        per_q = (time.perf_counter() - tq) / 2
-        n_sample = int(max(4, min(Q, args.cpu_seconds / max(per_q, 1e-6))))
-        tq = time.perf_counter()
-        oracle.bench_besthit_codes(subj, my_q[:n_sample], D)
-        dt = time.perf_counter() - tq
+        b = cpu_baselines(N, L, D, args.alphabet, subj, my_q, args.cpu_seconds)
         cpu = {
-            "value": n_sample / dt, "unit": "query seqs/s", "cores": 1, "kind": "port",
-            "sample": "first %d queries of the same batch against the same %d x %d %s store; oracle C port of "
-                      "src/lib.rs:238 (distances) + :298 (min) + :307 (equality pass), gcc -O3, 1 thread, "
-                      "contiguous store" % (n_sample, N, L, args.alphabet),
-            "host_cores_available": os.cpu_count(),
+            "value": b["b1"]["value"], "unit": "query seqs/s", "cores": 1, "kind": "port",
+            "sample": "B1: first %d queries of a %d x %d nucleotide batch against a %d-row one-hot store (5-bit codes, "
+                      "12 per u64 — src/lib.rs:29-52), oracle C port of src/lib.rs:238 (distances) + :298 (min) + :307 "
+                      "(equality pass), gcc -O3 without POPCNT (cargo's release default), 1 thread — the reference is "
+                      "single-threaded" % (b["b1"]["queries"], 512, L, N),
+            "cpu_model": b["cpu_model"], "host_cores_available": b["nproc"],
+            "b1": b["b1"], "b1n": b["b1n"], "b2": b["b2"],
         }
+        if "aa_code_bytes" in b:
+            cpu["aa_code_bytes"] = b["aa_code_bytes"]
 
     if rank == 0:
         q_total = Q * world
@@ -273,23 +479,35 @@ def main() -> None:
         # B_s = L x bits per symbol / 8 — aa 8 bits (60 B), nt 2 bits (15 B), nt with N 3 planes (22.5 B)
         sym_bits = 8 if args.alphabet == "aa" else int(info.planes)
         alg_bytes = pairs_per_launch * L * sym_bits // 8
-        achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
-        filt = os.environ.get("SMAFA_FILTER", "1") != "0"  # the timed steps run with the library default
-        W_, P_ = info.words_per_plane, info.planes
-        # VALU wave-instructions per (query, subject) pair = lane-ops per pair.  Prefilter fast path, per lane and
-        # query: 4 subjects x W xor/bitop3 + 2 and + 2 popcounts (one per two subjects) + or + compare + LDS
-        # address add = 4W + 7 per 4 pairs.  Full comparison: 4 subjects x (P*W xor/bitop3 + W popcounts) + 4 compares.
-        ops_per_pair = (W_ + 1.75) if filt else (P_ * W_ + W_ + 1.0)
-        if filt and plan["filter_plane_resident"]:
-            # level-1 bound only, 4T subjects per lane: 4T xor + 4T popcounts + 2T or3 + compare + LDS address
-            T_ = plan["tiles_per_wave"]
-            ops_per_pair = (10.0 * T_ + 2.0) / (4.0 * T_)
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc_path) and (N, L, Q, D, args.alphabet) == (10_000_000, 60, 10_000, 5, "aa"):
-            traffic = json.load(open(pmc_path))["batched_launch"]["hbm_bytes"]  # measured per launch, same workload
+        k_s = kernel_ms_avg * 1e-3
+        # VALU instructions and HBM traffic per launch: from the committed counter profile of this command, if it was
+        # taken on this workload and kernel (rocprofv3 cannot run inside the timed process)
+        pmc, pmc_note = None, "no counter profile for this workload: instruction count from the kernel's instruction model"
+        if os.path.exists(PMC_JSON):
+            rec_all = json.load(open(PMC_JSON))
+            for rec_ in rec_all.get("records", []):
+                c = rec_.get("config", {})
+                if ((c.get("db_rows"), c.get("seq_len"), c.get("queries"), c.get("max_div"), c.get("alphabet"), c.get("store"))
+                        == (N, L, Q, D, args.alphabet, args.store) and rec_.get("kernel") == kernel_name):
+                    pmc = rec_
+            if pmc:
+                pmc_note = ("profiles/r02_pmc.json: rocprofv3 --pmc passes of this bench command (tools/collect_pmc.py), "
+                            "per launch of %s; recorded from build %s, this run is build %s"
+                            % (kernel_name, pmc.get("build_id"), smafa_amd.build_id()))
+        filt = os.environ.get("SMAFA_FILTER", "1") != "0"
+        if pmc:
+            valu_insts = float(pmc["per_launch"]["SQ_INSTS_VALU"])
+        else:
+            W_, P_ = info.words_per_plane, info.planes
+            ops_per_pair = (W_ + 1.75) if filt else (P_ * W_ + W_ + 1.0)
+            if filt and plan["filter_plane_resident"]:
+                T_ = plan["tiles_per_wave"]
+                ops_per_pair = (10.0 * T_ + 2.0) / (4.0 * T_)
+            valu_insts = pairs_per_launch * ops_per_pair / 64.0
+        lane_ops = valu_insts * 64.0 / k_s
+        traffic = float(pmc["per_launch"]["hbm_bytes"]) if pmc and "hbm_bytes" in pmc["per_launch"] else None
         out = {
-            "metric": "query seqs/sec (DB residues/sec in `residues_per_s`) vs HBM roofline, %dM x %d%s DB, d<=%d"
+            "metric": "query seqs/sec (DB residues/sec in `residues_per_s`) vs roofline, %dM x %d%s DB, d<=%d"
                       % (N // 1_000_000, L, args.alphabet, D),
             "value": value,
             "unit": "query seqs/s",
@@ -303,61 +521,65 @@ def main() -> None:
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": "%d x %d %s subject store (uniform letters, 1%% duplicate rows, seed %d%s) replicated per GPU; "
-                            "%d planted queries per GPU per step (0..%d substitutions, seed 3); max-divergence %d"
-                            % (N, L, args.alphabet, 1 if alphabet else 2,
-                               ", N with probability %g per column" % args.n_frac if args.n_frac else "", Q, max_subs, D),
+                "workload": ("%d x %d %s subject store (%s) replicated per GPU; %d planted queries per GPU per step "
+                             "(0..%d substitutions, seed 3); max-divergence %d"
+                             % (N, L, args.alphabet,
+                                "related families: 100 members at 10-25 %% divergence from their root, seed 7"
+                                if args.store == "related" else
+                                "uniform letters, 1%% duplicate rows, seed %d%s" % (
+                                    1 if alphabet else 2,
+                                    ", N with probability %g per column" % args.n_frac if args.n_frac else ""),
+                                Q, max_subs, D)),
                 "db_rows": N, "seq_len": L, "alphabet": args.alphabet, "queries_per_gpu": Q, "max_divergence": D,
+                "store": args.store,
                 "parallelism": "query shards x%d, DB replicated, RCCL all_gather of row lists" % world,
             },
             "residues_per_s": value * N * L,
             "pairs_per_s": value * N,
             "rows_per_step": n_rows,
             "verified": ok,
+            "checks": checks,
+            "build_id": smafa_amd.build_id(),
             "roofline": {
-                "bound": "hbm",
-                # the instantiation rocprofv3 lists (profiles/r01_d_kernel_stats.csv): <PS, PQ, W, T, SEED>
-                "kernel": "smafa::%s<%d, %d, %d, %d, false>" % (
-                    "scan_lazy_kernel" if plan["filter_plane_resident"] else "scan_kernel", info.planes,
-                    5 if args.alphabet == "aa" else 3, info.words_per_plane, plan["tiles_per_wave"]),
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + "
-                                  "WRITE_SIZE, bytes per launch)" if traffic else None,
+                "bound": "valu",
+                "kernel": kernel_name,
+                "achieved": lane_ops / 1e12,
+                "peak": VALU_PEAK_LANE_OPS / 1e12,
+                "unit": "Tlane-op/s",
+                "frac": lane_ops / VALU_PEAK_LANE_OPS,
                 "kernel_ms_avg": kernel_ms_avg,
+                "valu_insts_per_launch": valu_insts,
+                "insts_source": pmc_note,
+                "insts_source_is_this_build": bool(pmc and pmc.get("build_id") == smafa_amd.build_id()),
+                "traffic": traffic,
+                "traffic_source": ("recorded in profiles/r02_pmc.json (FETCH_SIZE x 2 by the guide's gfx950 rule + "
+                                   "WRITE_SIZE, separate --pmc passes), NOT measured in this run") if traffic else None,
+                "hbm_frac_from_recorded_traffic": (traffic / k_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "algorithmic bytes = queries x subjects x %g B (SURVEY 8d). The kernel keeps a 1024-subject "
-                        "tile in registers and walks a whole query block over it, so the store is streamed from HBM "
-                        "once per query block, not once per query (see `traffic`): frac > 1 is register-level reuse "
-                        "plus the exact lower-bound prefilter, NOT HBM efficiency. The real ceiling of this kernel "
-                        "is VALU issue (see `valu`); the HBM-bound form (one query per pass) is in `stream`." % (L * sym_bits / 8),
-                "valu": {
-                    "prefilter": filt,
-                    "plan": plan,
-                    "lane_ops_per_pair": ops_per_pair,
-                    "achieved_lane_ops": pairs_per_launch * ops_per_pair / (kernel_ms_avg * 1e-3),
-                    "peak_lane_ops": VALU_PEAK_LANE_OPS,
-                    "frac": pairs_per_launch * ops_per_pair / (kernel_ms_avg * 1e-3) / VALU_PEAK_LANE_OPS,
-                    "note": "peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; measured issue rates on this chip "
-                            "(profiles/r01_ubench_valu*.txt): all-VGPR xor/bitop3/add ~60e12, v_bcnt/v_cmp/v_min and "
-                            "any op with an SGPR source ~37e12 lane-ops/s",
-                },
+                "algorithmic_reuse_x": alg_bytes / k_s / 1e9 / HBM_PEAK_GBS,
+                "plan": plan,
+                "prefilter": filt,
                 "stored_bytes_per_subject": int(info.bytes_per_subject),
-                "streamed_bytes_per_subject": int(info.words_per_plane * 4 if plan["filter_plane_resident"] else info.bytes_per_subject),
+                "note": "integer compare/reduce: the launch is bound by VALU issue, not HBM. peak = 256 CU x 4 SIMD x "
+                        "32 lanes x 2.4 GHz (one wave64 op per 2 cycles); measured issue rates on this chip "
+                        "(profiles/r01_ubench_valu*.txt): all-VGPR xor/bitop3/add ~60e12, v_bcnt/v_cmp and any op with "
+                        "an SGPR source ~37e12 lane-ops/s. algorithmic_reuse_x = queries x subjects x %g B (SURVEY 8d) "
+                        "over kernel time over 8 TB/s: how many times the naive one-query-per-pass traffic would "
+                        "exceed HBM peak — register reuse of a tile across a query block plus exact early-outs, NOT "
+                        "an HBM efficiency; the HBM-bound form is in `stream`." % (L * sym_bits / 8),
             },
             "stream": stream_info,
             "unfiltered": unfiltered,
+            "related": related,
             "host_api": host_api,
             "cpu_baseline": cpu,
             "setup_s": {"generate": t_gen, "pack_upload": t_up},
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -70,6 +70,12 @@ int smafa_device_count(void); /* 0 when no MI355X is visible; never fails */
  * 320-323; src/cluster.rs:33,87-92): 0 = errors only (--quiet), 1 = info (default of the reference), 2 = debug (-v).
  * The library default is 0 so that stderr stays clean for hosts that do not ask. */
 void smafa_set_verbosity(int level);
+/* Short hash of the kernel sources this library was built from (recorded beside profiles, so a bench run can tell
+ * whether a committed counter profile belongs to the binary it is timing). */
+const char *smafa_build_id(void);
+/* Measurement helper: the device's empirical HBM read-stream rate in GB/s — a trivial sum kernel over
+ * `bytes` (use >= 4 GiB: far more than the 256 MiB Infinity Cache), best of a few repetitions. */
+int smafa_hbm_read_probe(int device, uint64_t bytes, double *gb_per_s);
 
 /* ----------------------------------------------------------------- encoding */
 /* Replaces create_lut/BYTE_LUT/encode_single (src/lib.rs:167-196) and the per-byte half of
@@ -137,6 +143,9 @@ int smafa_last_scan_ms(smafa_db *db, float *ms, uint32_t *n_launches);
  * of each subject resident (then a sparse-hit scan streams words_per_plane*4 bytes per subject instead of
  * bytes_per_subject), wave tiles per wave, and query blocks (= passes over the store). */
 int smafa_last_scan_plan(smafa_db *db, uint32_t *filter_plane_resident, uint32_t *tiles_per_wave, uint32_t *query_blocks);
+/* Name of the scan kernel instantiation the most recent launch on this handle used, spelled the way rocprofv3
+ * lists it (e.g. "smafa::scan_lazy_kernel<5, 5, 2, 4, false>"), so that a bench line and a profile can be matched. */
+int smafa_last_scan_kernel(smafa_db *db, char *name, uint64_t cap);
 /* Tuning knob: queries per workgroup pass (0 = automatic). */
 int smafa_set_query_block(smafa_db *db, uint32_t queries_per_block);
 /* 1 (default): the scan evaluates an exact lower bound first and runs the full comparison only where it can

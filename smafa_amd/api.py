@@ -28,6 +28,17 @@ def device_count() -> int:
     return lib().smafa_device_count()
 
 
+def build_id() -> str:
+    return lib().smafa_build_id().decode()
+
+
+def hbm_read_probe(device: int = 0, nbytes: int = 8 << 30) -> float:
+    """Empirical HBM read-stream rate of the device in GB/s (a trivial sum kernel over `nbytes`)."""
+    out = C.c_double(0.0)
+    check(lib().smafa_hbm_read_probe(device, nbytes, C.byref(out)))
+    return out.value
+
+
 def encode(seq: bytes, alphabet: int = ALPHABET_NT) -> np.ndarray:
     """ASCII -> code bytes (create_lut / from_bytes, src/lib.rs:29-52,167-196)."""
     out = np.empty(len(seq), dtype=np.uint8)
@@ -154,6 +165,11 @@ class SubjectStore:
         a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
         check(lib().smafa_last_scan_plan(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"filter_plane_resident": bool(a.value), "tiles_per_wave": b.value, "query_blocks": c.value}
+
+    def last_scan_kernel(self) -> str:
+        buf = C.create_string_buffer(128)
+        check(lib().smafa_last_scan_kernel(self._h, buf, 128))
+        return buf.value.decode()
 
     def close(self):
         if self._h:

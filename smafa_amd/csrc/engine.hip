@@ -5,6 +5,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdarg>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -77,6 +79,7 @@ struct smafa_db {
     uint32_t wide_from = 5;       // words per plane from which scan_wide_kernel replaces the per-length kernels (SMAFA_WIDE_FROM)
     // what the last launch used (smafa_last_scan_plan)
     uint32_t plan_lazy = 0, plan_tiles = 1, plan_qblocks = 1;
+    char plan_kernel[96] = "";  // the instantiation of the last launch, as rocprofv3 names it (smafa_last_scan_kernel)
     int n_cu = 256;
     // scratch of the host-buffer API, kept across calls
     DevBuf upload;            // staging for code rows on their way to the pack kernel
@@ -192,8 +195,18 @@ static int qset_fill(smafa_qset *qs, smafa_db *db, const uint8_t *query_codes, u
     return pack_rows(db, query_codes, 0, n_queries, qs->qrec.as<uint32_t>(), 1);
 }
 
+// remember which instantiation ran, spelled the way rocprofv3 lists it
+static void note_kernel(const smafa_db *db, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+static void note_kernel(const smafa_db *db, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(const_cast<smafa_db *>(db)->plan_kernel, sizeof db->plan_kernel, fmt, ap);
+    va_end(ap);
+}
+
 template <int PS, int PQ, int W, int T>
 static void launch_lazy_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
+    note_kernel(db, "smafa::scan_lazy_kernel<%d, %d, %d, %d, %s>", PS, PQ, W, T, a.hits == nullptr && a.k_tight == 1 ? "true" : "false");
     if (a.hits == nullptr && a.k_tight == 1)
         hipLaunchKernelGGL((scan_lazy_kernel<PS, PQ, W, T, true>), dim3(grid), dim3(256), 0, db->stream,
                            reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
@@ -205,6 +218,7 @@ static void launch_lazy_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
 template <int PS, int PQ, int W, int T>
 static void launch_scan_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
     // the seed pass of the running-minimum mode (no append) has its own instantiation
+    note_kernel(db, "smafa::scan_kernel<%d, %d, %d, %d, %s>", PS, PQ, W, T, a.hits == nullptr && a.k_tight == 1 ? "true" : "false");
     if (a.hits == nullptr && a.k_tight == 1)
         hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, true>), dim3(grid), dim3(256), 0, db->stream,
                            reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
@@ -274,6 +288,7 @@ static void launch_wide_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
     const uint32_t wc = (db->W == 3 || db->W == 4) ? db->W : 0u;  // compile-time word count: register-resident dense walk
 #define SMAFA_WIDE(FW_, WC_)                                                                                     \
     if (fw == FW_ && wc == WC_) {                                                                               \
+        note_kernel(db, "smafa::scan_wide_kernel<%d, %d, %s, %d, %d>", PS, PQ, seed ? "true" : "false", FW_, WC_); \
         if (seed)                                                                                               \
             hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, true, FW_, WC_>), dim3(grid), dim3(256), 0, db->stream, \
                                planes, d_qrec, a, db->W);                                                       \
@@ -317,6 +332,7 @@ static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanAr
     SMAFA_CASE(5, 5, 1, 2) SMAFA_CASE(5, 5, 2, 2)
     SMAFA_CASE(2, 3, 1, 4) SMAFA_CASE(2, 3, 2, 4)
 #undef SMAFA_CASE
+    note_kernel(db, "smafa::scan_generic_kernel");
     hipLaunchKernelGGL(scan_generic_kernel, dim3(grid), dim3(256), 0, db->stream,
                        reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a, db->P, db->PQ, db->W, db->QS);
 }
@@ -824,6 +840,61 @@ int smafa_last_scan_plan(smafa_db *db, uint32_t *filter_plane_resident, uint32_t
     if (tiles_per_wave) *tiles_per_wave = db->plan_tiles;
     if (query_blocks) *query_blocks = db->plan_qblocks;
     return SMAFA_OK;
+}
+
+int smafa_last_scan_kernel(smafa_db *db, char *name, uint64_t cap) {
+    if (!db || !name || cap == 0) return set_error(SMAFA_ERR_INVALID, "smafa_last_scan_kernel: NULL argument");
+    snprintf(name, (size_t)cap, "%s", db->plan_kernel);
+    return SMAFA_OK;
+}
+
+int smafa_hbm_read_probe(int device, uint64_t bytes, double *gb_per_s) {
+    if (!gb_per_s) return set_error(SMAFA_ERR_INVALID, "smafa_hbm_read_probe: NULL argument");
+    *gb_per_s = 0.0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return set_error(SMAFA_ERR_DEVICE, "no HIP device visible: the smafa scan engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return set_error(SMAFA_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    bytes = std::max<uint64_t>(bytes, 1ull << 20) / 16 * 16;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    uint4 *d = nullptr;
+    uint32_t *out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e == hipSuccess) e = hipMalloc(&out, 4);
+    if (e == hipSuccess) e = hipMemset(d, 1, bytes);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float best = 0.f;
+    for (int per_cu : {8, 32}) {
+        const int grid = prop.multiProcessorCount * per_cu;
+        for (int rep = 0; rep < 4 && e == hipSuccess; rep++) {  // the first repetition of each shape warms up
+            e = hipEventRecord(e0, nullptr);
+            hipLaunchKernelGGL(hbm_read_probe_kernel, dim3(grid), dim3(256), 0, nullptr, d, (size_t)(bytes / 16), out);
+            if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e == hipSuccess && rep > 0 && ms > 0.f && (best == 0.f || ms < best)) best = ms;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d) (void)hipFree(d);
+    if (out) (void)hipFree(out);
+    if (e != hipSuccess) return set_error(SMAFA_ERR_DEVICE, "HBM read probe failed: %s", hipGetErrorString(e));
+    if (best > 0.f) *gb_per_s = (double)bytes / ((double)best * 1e-3) / 1e9;
+    return SMAFA_OK;
+}
+
+const char *smafa_build_id(void) {
+#ifdef SMAFA_BUILD_ID
+    return SMAFA_BUILD_ID;
+#else
+    return "unknown";
+#endif
 }
 
 int smafa_set_prefilter(smafa_db *db, int enabled) {

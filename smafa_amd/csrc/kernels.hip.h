@@ -1258,6 +1258,23 @@ __global__ void kth_from_counts_kernel(const uint32_t *cnt, uint32_t cnt_stride,
     }
 }
 
+// Empirical HBM read-stream ceiling of the device ("measure an empirical read-stream ceiling on the box with
+// a trivial sum kernel over a >= 4 GB buffer"): 16-byte loads per lane, grid-stride, 8 loads in flight per lane.
+__global__ __launch_bounds__(256) void hbm_read_probe_kernel(const uint4 *__restrict__ p, size_t n, uint32_t *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i + 7 * stride < n; i += 8 * stride) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < n; i += stride) acc += p[i].x;
+    if (acc == 0x12345678u) out[0] = acc;  // keeps the loads alive
+}
+
 __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

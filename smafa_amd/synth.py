@@ -36,6 +36,31 @@ def subjects(n: int, seq_len: int = 60, alphabet: int = 1, seed: int = 1, dup_fr
     return out
 
 
+def related_subjects(n_families: int, members: int = 100, seq_len: int = 60, alphabet: int = 1, seed: int = 7,
+                     div_lo: float = 0.10, div_hi: float = 0.25) -> np.ndarray:
+    """A store of homologous sequences: n_families uniform roots, `members` members each; a member is its root
+    with every column substituted (to a different letter) with the member's own probability, uniform in
+    [div_lo, div_hi]; rows shuffled.  Two members of a family then differ in roughly 20-45 % of their columns —
+    close enough that a one-plane lower bound cannot separate them cheaply, far enough that few are hits."""
+    rng = np.random.default_rng(seed)
+    lc = letter_codes(alphabet)
+    roots = rng.integers(0, len(lc), size=(n_families, seq_len), dtype=np.uint8)  # indices into lc
+    n = n_families * members
+    out = np.empty((n, seq_len), dtype=np.uint8)
+    step = max(1, (1 << 20) // members)  # families per chunk (~1M rows)
+    for f0 in range(0, n_families, step):
+        f1 = min(n_families, f0 + step)
+        idx = np.repeat(roots[f0:f1], members, axis=0)
+        rows = len(idx)
+        div = rng.uniform(div_lo, div_hi, size=rows)
+        hit = rng.integers(0, 1 << 16, size=(rows, seq_len), dtype=np.uint16) < (div * 65536.0).astype(np.uint32)[:, None]
+        shift = rng.integers(1, len(lc), size=(rows, seq_len), dtype=np.uint8)
+        idx = np.where(hit, (idx + shift) % len(lc), idx).astype(np.uint8)
+        out[f0 * members:f1 * members] = lc[idx]
+    rng.shuffle(out, axis=0)
+    return out
+
+
 def queries(subject_codes: np.ndarray, q: int, alphabet: int = 1, seed: int = 3, max_subs: int = 10):
     """-> (query codes, planted subject row, number of substitutions)"""
     rng = np.random.default_rng(seed)

@@ -138,3 +138,40 @@ def test_sharded_cluster_equals_oracle_and_single_rank(tmp_path, world):
     finally:
         os.close(fd)
     assert open(single).read() == want.stdout
+
+
+# ---- bench.py --gpus N from a plain shell: the process starts its own ranks
+def _bench(*flags, timeout=600):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True,
+                          env=env, timeout=timeout)
+
+
+def test_bench_self_launch_spawns_ranks_on_cpu_only_host():
+    """No GPU here: the parent must still have spawned torch.distributed.run with 2 ranks, each of which refuses to
+    run without a HIP device (the engine has no CPU fallback) — the parent relays the failure."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("host has a GPU: covered by the gpu test below")
+    r = _bench("--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--db-rows", "1000", "--queries", "8",
+               "--no-cpu-baseline", "--no-stream")
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a HIP device") >= 2, r.stderr[-2000:]
+    assert "WORLD_SIZE" not in r.stderr  # the old refusal ("launch with torch.distributed.run") is gone
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks_one_gpu_gloo():
+    import json
+
+    r = _bench("--gpus", "2", "--single-device", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--db-rows", "200000",
+               "--queries", "512", "--no-cpu-baseline", "--no-related")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["verified"] is True and out["steps"] == 2
+    assert out["roofline"]["bound"] == "valu" and 0 < out["roofline"]["frac"] <= 1.0

@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Collect the rocprofv3 evidence bench.py's `roofline` block cites, on the GPU box:
+
+    python3 tools/collect_pmc.py [--tag NAME] [-- extra bench.py flags]
+
+  1. `rocprofv3 --kernel-trace --stats` of `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-stream`
+     -> per-kernel average durations (must agree with the HIP-event average of the bench line);
+  2. four separate `--pmc` passes of the same command (counters never share a run with a trace other than the
+     kernel trace, and FETCH_SIZE / WRITE_SIZE cannot share a pass — MI355X_MICROARCH.md, PMC slots):
+     SQ instruction/cycle counters (two passes), FETCH_SIZE, WRITE_SIZE;
+  3. per-launch averages over the dispatches of the bench line's dominant kernel, HBM bytes by the guide's rule
+     (FETCH_SIZE is KiB and reads HALF of a wide streaming read on gfx950: bytes = FETCH_SIZE * 1024 * 2,
+     plus WRITE_SIZE * 1024), derived issue figures.
+Everything lands under gpurun_out/<tag>/ (scratch); the summary JSON is gpurun_out/<tag>/pmc_record.json — copy it
+into profiles/r02_pmc.json ("records": [...]) to have bench.py use it.
+The program after `--` is python3 itself: no env/bash hop between rocprofv3 and the process that opens the GPU.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SQ_A = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
+        "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY"]
+SQ_B = ["GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_LDS_BANK_CONFLICT",
+        "SQ_WAIT_ANY", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD"]
+
+
+def run(cmd, log):
+    with open(log, "w") as f:
+        r = subprocess.run(cmd, stdout=f, stderr=subprocess.STDOUT, cwd=ROOT)
+    return r.returncode
+
+
+def bench_line(log):
+    for line in open(log, errors="replace"):
+        line = line.strip()
+        if line.startswith("{") and '"metric"' in line:
+            return json.loads(line)
+    return None
+
+
+def counter_rows(out_dir):
+    rows = []
+    for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as f:
+            rows.extend(csv.DictReader(f))
+    return rows
+
+
+def per_launch(rows, kernel_sub):
+    """average counter value per dispatch of the kernel, over its full-size dispatches"""
+    mine = [r for r in rows if kernel_sub in r["Kernel_Name"]]
+    if not mine:
+        return {}, 0, 0.0
+    grid = max(int(r["Grid_Size"]) for r in mine)
+    mine = [r for r in mine if int(r["Grid_Size"]) == grid]
+    disp = {}
+    for r in mine:
+        disp.setdefault(r["Dispatch_Id"], {})[r["Counter_Name"]] = float(r["Counter_Value"])
+        disp[r["Dispatch_Id"]]["_ns"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    names = sorted({k for d in disp.values() for k in d if not k.startswith("_")})
+    avg = {n: sum(d.get(n, 0.0) for d in disp.values()) / len(disp) for n in names}
+    ms = sum(d["_ns"] for d in disp.values()) / len(disp) / 1e6
+    return avg, len(disp), ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", default="r02_prof")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--skip-stats", action="store_true")
+    ap.add_argument("bench_args", nargs="*", help="extra bench.py flags (after --)")
+    a = ap.parse_args()
+    out = os.path.join(ROOT, "gpurun_out", a.tag)
+    os.makedirs(out, exist_ok=True)
+    os.environ.setdefault("TMPDIR", "/tmp")
+    bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "2", "--no-cpu-baseline",
+             "--no-stream", *a.bench_args]
+    prof = "/opt/rocm/bin/rocprofv3"
+
+    record = {"command": " ".join(bench[1:]).replace(ROOT + "/", "")}
+    if not a.skip_stats:
+        rc = run([prof, "--kernel-trace", "--stats", "-d", os.path.join(out, "stats"), "-o", "stats", "--output-format", "csv",
+                  "--", *bench], os.path.join(out, "stats.log"))
+        print("stats pass rc", rc, flush=True)
+        line = bench_line(os.path.join(out, "stats.log"))
+        if line:
+            record["bench_under_kernel_trace"] = {k: line[k] for k in ("value", "ms_per_step", "verified")}
+            record["kernel_ms_avg_hip_events_under_trace"] = line["roofline"]["kernel_ms_avg"]
+        for path in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+            with open(path, newline="") as f:
+                record["kernel_stats"] = [r for r in csv.DictReader(f)][:12]
+    passes = [("sq_a", SQ_A), ("sq_b", SQ_B), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])]
+    merged, n_disp, kernel, cfg, ms_prof = {}, {}, None, None, {}
+    for name, counters in passes:
+        d = os.path.join(out, name)
+        rc = run([prof, "--pmc", *counters, "--kernel-trace", "-d", d, "-o", name, "--output-format", "csv", "--", *bench],
+                 os.path.join(out, name + ".log"))
+        print(name, "pass rc", rc, flush=True)
+        line = bench_line(os.path.join(out, name + ".log"))
+        if not line:
+            print("no bench line in", name, "— see", os.path.join(out, name + ".log"))
+            continue
+        kernel = line["roofline"]["kernel"]
+        cfg = line["config"]
+        record["build_id"] = line.get("build_id")
+        avg, nd, ms = per_launch(counter_rows(d), kernel.replace("smafa::", ""))
+        merged.update(avg)
+        n_disp[name] = nd
+        ms_prof[name] = ms
+    if not merged:
+        print("no counters collected")
+        return 1
+    if "FETCH_SIZE" in merged:
+        merged["hbm_bytes"] = merged["FETCH_SIZE"] * 1024.0 * 2.0 + merged.get("WRITE_SIZE", 0.0) * 1024.0
+    record.update({
+        "kernel": kernel,
+        "config": {"db_rows": cfg["db_rows"], "seq_len": cfg["seq_len"], "queries": cfg["queries_per_gpu"],
+                   "max_div": cfg["max_divergence"], "alphabet": cfg["alphabet"], "store": cfg.get("store", "uniform")},
+        "per_launch": merged,
+        "dispatches_averaged": n_disp,
+        "kernel_ms_under_profiler": ms_prof,
+        "unit_note": "FETCH_SIZE/WRITE_SIZE are KiB; gfx950 FETCH_SIZE counts half of a wide coalesced streaming read "
+                     "(MI355X_MICROARCH.md): hbm_bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024",
+    })
+    pairs = cfg["db_rows"] * cfg["queries_per_gpu"]
+    ms = ms_prof.get("sq_a") or 0.0
+    if "SQ_INSTS_VALU" in merged and ms:
+        steps = pairs / 1024.0
+        clock = merged.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / (ms_prof.get("sq_b") or ms) / 1e6  # GHz
+        derived = {
+            "valu_wave_instructions_per_1024_pairs": merged["SQ_INSTS_VALU"] / steps,
+            "salu_per_1024_pairs": merged.get("SQ_INSTS_SALU", 0.0) / steps,
+            "lds_per_1024_pairs": merged.get("SQ_INSTS_LDS", 0.0) / steps,
+            "lane_ops_per_s": merged["SQ_INSTS_VALU"] * 64.0 / (ms * 1e-3),
+            "clock_GHz": clock,
+        }
+        cycles = merged.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # per XCD: rocprofv3 sums the 8 XCDs
+        if cycles:
+            # 1024 SIMDs; SQ_WAVE_CYCLES counts in units of 4 cycles (matches the round-1 derivation, r01_pmc_sq.json)
+            derived["cycles_per_valu_instruction_per_simd"] = cycles * 1024.0 / merged["SQ_INSTS_VALU"]
+            derived["salu_instructions_per_cycle_per_cu"] = merged.get("SQ_INSTS_SALU", 0.0) / 256.0 / cycles
+            if merged.get("SQ_WAVE_CYCLES"):
+                derived["resident_waves_per_simd"] = merged["SQ_WAVE_CYCLES"] * 4.0 / (cycles * 1024.0)
+            if merged.get("SQ_WAIT_INST_ANY") and merged.get("SQ_WAVE_CYCLES") and merged.get("SQ_ACTIVE_INST_ANY"):
+                wc = merged["SQ_WAVE_CYCLES"]
+                derived["wave_time_split"] = {
+                    "waiting (s_waitcnt/barrier)": merged.get("SQ_WAIT_ANY", 0.0) / wc,
+                    "issuing": merged["SQ_ACTIVE_INST_ANY"] / wc,
+                }
+        record["derived"] = derived
+    path = os.path.join(out, "pmc_record.json")
+    json.dump(record, open(path, "w"), indent=1)
+    print("wrote", path)
+    print(json.dumps({k: record[k] for k in ("kernel", "config", "build_id")}))
+    print(json.dumps(record.get("derived", {}), indent=1))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
