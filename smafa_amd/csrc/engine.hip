@@ -25,6 +25,9 @@ namespace smafa {
 // planes per query record: 3 code bits for ACGTN, 5 for the amino-acid codes 0..27
 static int query_planes_for(int alphabet) { return alphabet == SMAFA_ALPHABET_AA ? 5 : 3; }
 
+// row counter (u64) at byte 0, ticket counters of finish_rows from byte 256 on
+constexpr size_t kCtrBytes = 256 + (size_t)(1 + kTicketGroups) * kTicketStride * sizeof(uint32_t);
+
 // grow-only device buffer (scratch that is reused across calls: hipMalloc/hipFree cost far more than a scan)
 struct DevBuf {
     void *p = nullptr;
@@ -84,8 +87,22 @@ struct smafa_db {
     // scratch of the host-buffer API, kept across calls
     DevBuf upload;            // staging for code rows on their way to the pack kernel
     DevBuf hits, count;       // rows and their counter
-    DevBuf shard_rows, shard_counts;  // where the scan kernels append (kShards segments) before compaction
+    DevBuf scratch;           // row list of the tightening modes (everything appended while bounds were still running)
+    DevBuf ctrs;              // [0]: the scan kernels' row counter (u64), [256]: finished-workgroup tickets (u32); both zero between scans
     DevBuf keys_a, keys_b, sort_tmp;
+    DevBuf idx_a, idx_b;      // sort payload of an append: source row per sorted position
+    // ---- layout of the packed store (fixed when the first rows arrive)
+    bool layout_set = false;
+    std::vector<uint16_t> perm;  // packed column j holds source column perm[j]
+    std::vector<uint8_t> tab;    // [source column][code] -> stored code
+    DevBuf d_perm, d_tab;
+    uint32_t *d_order = nullptr;  // position -> subject index (cap_tiles * 256 entries)
+    uint4 *d_zone = nullptr;      // per wave tile: shared filter bits (cap_tiles entries)
+    struct Run { uint64_t rows; bool sorted; };
+    std::vector<Run> runs;        // the appends the store consists of (each sorted within itself or not)
+    int zone = 1;                 // zone level of the filter-plane-resident kernel: 1 = where it prunes (use_zone), 0 = never
+                                  // (SMAFA_ZONE=0), 2 = whenever that kernel runs (SMAFA_ZONE=2, tests)
+    bool sort_rows = true;        // sort big appends by their filter words (SMAFA_SORT=0: keep the append order)
     smafa_qset scratch_q;     // query set of smafa_scan_hits / smafa_distances
     smafa_qset scratch_q2;    // the compacted batch of queries the near-hit probe did not finish
     bool two_phase = true;    // near-hit probe before the tightening path (SMAFA_TWO_PHASE=0 disables)
@@ -108,27 +125,156 @@ static int use_device(const smafa_db *db) {
     return SMAFA_OK;
 }
 
-// upload code rows and pack them with the ballot kernel
+// ---- layout of a store: which source column sits in which packed column, and how each column's codes are re-coded.
+// Both leave every distance unchanged (a distance counts columns whose codes differ; neither the order of the columns
+// nor a per-column injective renaming of the codes changes that), so they are free parameters of the HBM layout, chosen
+// for the prefilter: plane 0 is the plane its lower bounds look at, packed columns 0..31 its first level.
+//   * per column, the letters are split into two sets of nearly equal total frequency (greedy, by descending count);
+//     the first set gets even codes, the second odd ones: bit 0 of the stored code then flips for a mismatch as often
+//     as this column's letter distribution allows.  Nucleotides: A C G T are permuted among 0..3 and N stays 4 (the
+//     2-plane form of an N-free store holds bits 0 and 1); of the three A/C/G/T pairings, {A,C}|{G,T} is preferred
+//     while it is within 5 % of the best — it is the one that sees transitions, the commonest real substitutions.
+//   * columns are ordered by that flip probability, 2p(1-p), best first: conserved columns end up in the last words.
+// Decided once per handle, from a sample of the first rows it receives.
+static int choose_layout(smafa_db *db, const uint8_t *codes, uint64_t n) {
+    const uint32_t L = db->L;
+    const bool aa = db->alphabet == SMAFA_ALPHABET_AA;
+    const uint32_t n_sym = aa ? 28u : 4u, side_cap = aa ? 16u : 2u;
+    std::vector<uint32_t> cnt((size_t)L * 32, 0);
+    const uint64_t S = std::min<uint64_t>(n, 4096);
+    for (uint64_t k = 0; k < S; k++) {
+        const uint8_t *row = codes + (size_t)(k * n / S) * L;
+        for (uint32_t c = 0; c < L; c++) cnt[(size_t)c * 32 + (row[c] & 31u)]++;
+    }
+    db->tab.assign((size_t)L * 32, 0);
+    std::vector<double> score(L, 0.0);
+    for (uint32_t c = 0; c < L; c++) {
+        const uint32_t *cc = &cnt[(size_t)c * 32];
+        uint8_t *tc = &db->tab[(size_t)c * 32];
+        for (uint32_t v = 0; v < 32; v++) tc[v] = (uint8_t)v;  // codes outside the movable set keep their value
+        uint32_t side_of[32];
+        uint64_t tot[2] = {0, 0};
+        auto balance = [&]() {
+            const double all = (double)(tot[0] + tot[1]);
+            return all > 0 ? 2.0 * (double)tot[0] * (double)tot[1] / (all * all) : 0.0;
+        };
+        if (!aa) {
+            // three pairings of A C G T (codes 0..3); side 1 listed
+            static const uint8_t pair[3][2] = {{2, 3}, {1, 3}, {1, 2}};  // {A,C}|{G,T}  {A,G}|{C,T}  {A,T}|{C,G}
+            double sc[3];
+            for (int k = 0; k < 3; k++) {
+                tot[1] = (uint64_t)cc[pair[k][0]] + cc[pair[k][1]];
+                tot[0] = (uint64_t)cc[0] + cc[1] + cc[2] + cc[3] - tot[1];
+                sc[k] = balance();
+            }
+            int best = 0;
+            const double top = std::max(sc[0], std::max(sc[1], sc[2]));
+            if (sc[0] < 0.95 * top) best = sc[1] >= sc[2] ? 1 : 2;
+            for (uint32_t v = 0; v < 4; v++) side_of[v] = (v == pair[best][0] || v == pair[best][1]) ? 1u : 0u;
+            score[c] = sc[best];
+        } else {
+            uint32_t idx[32], num[2] = {0, 0};
+            for (uint32_t v = 0; v < n_sym; v++) idx[v] = v;
+            std::stable_sort(idx, idx + n_sym, [&](uint32_t x, uint32_t y) { return cc[x] > cc[y]; });
+            for (uint32_t k = 0; k < n_sym; k++) {
+                uint32_t side = tot[0] <= tot[1] ? 0u : 1u;
+                if (num[side] == side_cap) side ^= 1u;
+                side_of[idx[k]] = side;
+                tot[side] += cc[idx[k]];
+                num[side]++;
+            }
+            score[c] = balance();
+        }
+        uint32_t next[2] = {0, 1};  // even codes for side 0, odd for side 1, in code order
+        bool used[32] = {false};
+        for (uint32_t v = 0; v < n_sym; v++) {
+            tc[v] = (uint8_t)next[side_of[v]];
+            used[next[side_of[v]]] = true;
+            next[side_of[v]] += 2;
+        }
+        if (aa) {  // codes 28..31 never occur; keep the map a permutation anyway
+            uint32_t free_v = 0;
+            for (uint32_t v = n_sym; v < 32; v++) {
+                while (used[free_v]) free_v++;
+                tc[v] = (uint8_t)free_v;
+                used[free_v] = true;
+            }
+        }
+    }
+    std::vector<uint32_t> cols(L);
+    for (uint32_t c = 0; c < L; c++) cols[c] = c;
+    std::stable_sort(cols.begin(), cols.end(), [&](uint32_t x, uint32_t y) { return score[x] > score[y]; });
+    db->perm.assign((size_t)db->W * 32, 0);
+    for (uint32_t j = 0; j < L; j++) db->perm[j] = (uint16_t)cols[j];
+    int rc = db->d_perm.ensure(db->perm.size() * sizeof(uint16_t));
+    if (!rc) rc = db->d_tab.ensure(db->tab.size());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(db->d_perm.p, db->perm.data(), db->perm.size() * sizeof(uint16_t), hipMemcpyHostToDevice, db->stream));
+    HIP_TRY(hipMemcpyAsync(db->d_tab.p, db->tab.data(), db->tab.size(), hipMemcpyHostToDevice, db->stream));
+    HIP_TRY(hipStreamSynchronize(db->stream));  // the vectors may be reallocated later; the copy is done now
+    db->layout_set = true;
+    return SMAFA_OK;
+}
+
+template <int P>
+static void launch_pack(smafa_db *db, const uint8_t *d_codes, const uint32_t *d_src, uint64_t first, uint64_t n,
+                        uint32_t *d_out, int mode, uint32_t *d_order) {
+    const uint64_t groups = (first + n + 63) / 64 - first / 64;
+    const uint32_t blocks = (uint32_t)((groups + kWgWaves - 1) / kWgWaves);
+    hipLaunchKernelGGL(pack_rows_kernel<P>, dim3(blocks), dim3(256), 0, db->stream, d_codes, d_src, first, n, db->L, db->W,
+                       d_out, mode, db->QS, db->d_perm.as<uint16_t>(), db->d_tab.as<uint8_t>(), d_order);
+}
+
+constexpr uint64_t kSortMin = 4096;  // appends of fewer rows keep their order (their tiles share few bits anyway)
+
+// Upload code rows and pack them with the ballot kernel.  mode 0: subjects, at positions first.. of the store — big
+// appends are first sorted by their filter words (row_keys_kernel + a device radix sort), so that the subjects of a
+// wave tile share their leading filter bits (the zone level of the scan), and the zone words of the touched tiles are
+// recomputed; mode 1: query records, in the caller's order.
 static int pack_rows(smafa_db *db, const uint8_t *codes, uint64_t first, uint64_t n, uint32_t *d_out, int mode) {
     if (n == 0) return SMAFA_OK;
+    if (n > 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many rows in one call");
+    if (!db->layout_set) {
+        int lrc = choose_layout(db, codes, mode == 0 ? n : 0);  // a query batch says nothing about the subjects
+        if (lrc) return lrc;
+    }
     const size_t bytes = (size_t)n * db->L;
     int rc = db->upload.ensure(bytes);
     if (rc) return rc;
     uint8_t *d_codes = db->upload.as<uint8_t>();
     HIP_TRY(hipMemcpyAsync(d_codes, codes, bytes, hipMemcpyHostToDevice, db->stream));
-    const uint64_t groups = (first + n + 63) / 64 - first / 64;
-    const uint32_t blocks = (uint32_t)((groups + kWgWaves - 1) / kWgWaves);
+    const uint32_t *d_src = nullptr;
+    const bool sorted = mode == 0 && db->sort_rows && n >= kSortMin;
+    if (sorted) {
+        rc = db->keys_a.ensure(n * sizeof(unsigned long long));
+        if (!rc) rc = db->keys_b.ensure(n * sizeof(unsigned long long));
+        if (!rc) rc = db->idx_a.ensure(n * sizeof(uint32_t));
+        if (!rc) rc = db->idx_b.ensure(n * sizeof(uint32_t));
+        if (rc) return rc;
+        unsigned long long *ka = db->keys_a.as<unsigned long long>(), *kb = db->keys_b.as<unsigned long long>();
+        uint32_t *ia = db->idx_a.as<uint32_t>(), *ib = db->idx_b.as<uint32_t>();
+        hipLaunchKernelGGL(row_keys_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, db->stream, d_codes, n, db->L,
+                           db->d_perm.as<uint16_t>(), db->d_tab.as<uint8_t>(), ka, ia);
+        size_t tmp_bytes = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ka, kb, ia, ib, (int)n, 0, 64, db->stream));
+        rc = db->sort_tmp.ensure(tmp_bytes);
+        if (rc) return rc;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort_tmp.p, tmp_bytes, ka, kb, ia, ib, (int)n, 0, 64, db->stream));
+        d_src = ib;
+    }
     const uint32_t planes = mode == 0 ? db->P : db->PQ;  // subjects may be stored with fewer planes than queries
-    if (planes == 5)
-        hipLaunchKernelGGL(pack_rows_kernel<5>, dim3(blocks), dim3(256), 0, db->stream, d_codes, first, n, db->L, db->W,
-                           d_out, mode, db->QS);
-    else if (planes == 3)
-        hipLaunchKernelGGL(pack_rows_kernel<3>, dim3(blocks), dim3(256), 0, db->stream, d_codes, first, n, db->L, db->W,
-                           d_out, mode, db->QS);
-    else
-        hipLaunchKernelGGL(pack_rows_kernel<2>, dim3(blocks), dim3(256), 0, db->stream, d_codes, first, n, db->L, db->W,
-                           d_out, mode, db->QS);
+    uint32_t *d_order = mode == 0 ? db->d_order : nullptr;
+    if (planes == 5) launch_pack<5>(db, d_codes, d_src, first, n, d_out, mode, d_order);
+    else if (planes == 3) launch_pack<3>(db, d_codes, d_src, first, n, d_out, mode, d_order);
+    else launch_pack<2>(db, d_codes, d_src, first, n, d_out, mode, d_order);
     HIP_TRY(hipGetLastError());
+    if (mode == 0) {
+        const uint32_t t0 = (uint32_t)(first / kWaveTile), t1 = (uint32_t)((first + n + kWaveTile - 1) / kWaveTile);
+        hipLaunchKernelGGL(zone_kernel, dim3((t1 - t0 + kWgWaves - 1) / kWgWaves), dim3(256), 0, db->stream,
+                           reinterpret_cast<const uint4 *>(db->d_planes), db->P, db->W, t0, t1, (uint32_t)(first + n), db->d_zone);
+        HIP_TRY(hipGetLastError());
+        db->runs.push_back({n, sorted});
+    }
     // the caller's host buffer is borrowed for the call only, and `upload` is reused by the next call
     HIP_TRY(hipStreamSynchronize(db->stream));
     return SMAFA_OK;
@@ -167,18 +313,31 @@ static int reserve_tiles(smafa_db *db, uint64_t need_tiles) {
     uint64_t ncap = db->cap_tiles ? db->cap_tiles * 2 : 64;
     if (ncap < need_tiles) ncap = need_tiles;
     ncap = (ncap + kWgWaves - 1) / kWgWaves * kWgWaves;
-    uint32_t *d_new = nullptr;
+    uint32_t *d_new = nullptr, *d_order = nullptr;
+    uint4 *d_zone = nullptr;
     const size_t bytes = ncap * db->tile_words() * sizeof(uint32_t);
     HIP_TRY(hipMalloc(&d_new, bytes));
-    // zero-fill: padding subjects of the last tile read as all-zero planes and are masked by index
+    HIP_TRY(hipMalloc(&d_order, ncap * kWaveTile * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_zone, ncap * sizeof(uint4)));
+    // zero-fill: padding subjects of the last tile read as all-zero planes and are masked by position; a zero zone
+    // entry shares no bits (prunes nothing)
     HIP_TRY(hipMemsetAsync(d_new, 0, bytes, db->stream));
+    HIP_TRY(hipMemsetAsync(d_order, 0, ncap * kWaveTile * sizeof(uint32_t), db->stream));
+    HIP_TRY(hipMemsetAsync(d_zone, 0, ncap * sizeof(uint4), db->stream));
     if (db->d_planes) {
         HIP_TRY(hipMemcpyAsync(d_new, db->d_planes, db->cap_tiles * db->tile_words() * sizeof(uint32_t),
                                hipMemcpyDeviceToDevice, db->stream));
+        HIP_TRY(hipMemcpyAsync(d_order, db->d_order, db->cap_tiles * kWaveTile * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                               db->stream));
+        HIP_TRY(hipMemcpyAsync(d_zone, db->d_zone, db->cap_tiles * sizeof(uint4), hipMemcpyDeviceToDevice, db->stream));
         HIP_TRY(hipStreamSynchronize(db->stream));
         HIP_TRY(hipFree(db->d_planes));
+        HIP_TRY(hipFree(db->d_order));
+        HIP_TRY(hipFree(db->d_zone));
     }
     db->d_planes = d_new;
+    db->d_order = d_order;
+    db->d_zone = d_zone;
     db->cap_tiles = ncap;
     return SMAFA_OK;
 }
@@ -206,13 +365,26 @@ static void note_kernel(const smafa_db *db, const char *fmt, ...) {
 
 template <int PS, int PQ, int W, int T>
 static void launch_lazy_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
-    note_kernel(db, "smafa::scan_lazy_kernel<%d, %d, %d, %d, %s>", PS, PQ, W, T, a.hits == nullptr && a.k_tight == 1 ? "true" : "false");
-    if (a.hits == nullptr && a.k_tight == 1)
-        hipLaunchKernelGGL((scan_lazy_kernel<PS, PQ, W, T, true>), dim3(grid), dim3(256), 0, db->stream,
-                           reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
+    const bool seed = a.hits == nullptr && a.k_tight == 1;
+    note_kernel(db, "smafa::scan_lazy_kernel<%d, %d, %d, %d, %s>", PS, PQ, W, T, seed ? "true" : "false");
+    const uint4 *planes = reinterpret_cast<const uint4 *>(db->d_planes);
+    if (seed)
+        hipLaunchKernelGGL((scan_lazy_kernel<PS, PQ, W, T, true>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
     else
-        hipLaunchKernelGGL((scan_lazy_kernel<PS, PQ, W, T, false>), dim3(grid), dim3(256), 0, db->stream,
-                           reinterpret_cast<const uint4 *>(db->d_planes), d_qrec, a);
+        hipLaunchKernelGGL((scan_lazy_kernel<PS, PQ, W, T, false>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
+}
+
+// sorted store: the zone level in front (scan_zone_kernel; up to 64 queries per launch: scan_zone_few_kernel)
+template <int PS, int PQ, int W>
+static void launch_zone_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
+    const uint4 *planes = reinterpret_cast<const uint4 *>(db->d_planes);
+    if (a.q_end - a.q_begin <= 64u) {
+        note_kernel(db, "smafa::scan_zone_few_kernel<%d, %d, %d>", PS, PQ, W);
+        hipLaunchKernelGGL((scan_zone_few_kernel<PS, PQ, W>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
+        return;
+    }
+    note_kernel(db, "smafa::scan_zone_kernel<%d, %d, %d>", PS, PQ, W);
+    hipLaunchKernelGGL((scan_zone_kernel<PS, PQ, W>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
 }
 
 template <int PS, int PQ, int W, int T>
@@ -270,6 +442,43 @@ static bool use_wide(const smafa_db *db, uint32_t thr0) {
            wide_fits((int)db->PQ, (int)db->W);
 }
 
+// P(Binomial(bits, 1/2) <= bound): how often `bits` shared filter bits of a tile fail to exclude a random query
+static double binom_tail(uint32_t bits, uint32_t bound) {
+    if (bound >= bits) return 1.0;
+    double term = 1.0, tail = 0.0;
+    for (uint32_t k = 0; k <= bound; k++) {
+        tail += term;
+        term = term * (double)(bits - k) / (double)(k + 1);
+    }
+    for (uint32_t i = 0; i < bits; i++) tail *= 0.5;
+    return tail;
+}
+
+// Does the zone level pay?  An append of r rows that was sorted within itself leaves about log2(r / 256) - 1 shared
+// leading bits per wave tile (uniform letters; related sequences share more, so the estimate is conservative);
+// unsorted appends share none.  The zone level costs ~25 % when every (query, tile) pair passes it and saves up to
+// 4-5x when few do: use it while the estimated pass rate is below one half.
+static bool use_zone(const smafa_db *db, uint32_t thr0) {
+    if (db->zone != 1) return db->zone == 2;
+    double tiles = 0.0, pass = 0.0;
+    for (const smafa_db::Run &r : db->runs) {
+        const double t = (double)r.rows / kWaveTile;
+        uint32_t bits = 0;
+        if (r.sorted) {
+            uint64_t x = r.rows / kWaveTile;
+            while (x > 1) {
+                bits++;
+                x >>= 1;
+            }
+            bits = bits > 0 ? bits - 1 : 0;
+            bits = std::min(bits, std::min<uint32_t>(32u, db->L));
+        }
+        tiles += t;
+        pass += t * binom_tail(bits, thr0);
+    }
+    return tiles > 0.0 && pass / tiles < 0.5;
+}
+
 static uint32_t tiles_per_wave(const smafa_db *db, bool lazy) {
     if (lazy) return db->W >= 3 ? 2u : 4u;  // every filter word resident: 8 subjects per lane from 3 words on
     if (db->W > 2) return 1;
@@ -302,11 +511,21 @@ static void launch_wide_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
 }
 
 static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid, uint32_t T,
-                        bool lazy) {
+                        bool lazy, bool zone) {
     if (lazy && (db->W >= db->wide_from || (db->W == 1 && db->wide_one))) {  // above 64 columns, or up to 32
         if (db->P == 2) return launch_wide_t<2, 3>(db, d_qrec, a, grid);
         if (db->P == 3) return launch_wide_t<3, 3>(db, d_qrec, a, grid);
         return launch_wide_t<5, 5>(db, d_qrec, a, grid);
+    }
+    if (lazy && zone) {  // sorted store, bound the zone level prunes at
+#define SMAFA_ZONE(PS_, PQ_, W_)                                 \
+    if (db->P == PS_ && db->PQ == PQ_ && db->W == W_) {          \
+        launch_zone_t<PS_, PQ_, W_>(db, d_qrec, a, grid);        \
+        return;                                                  \
+    }
+        SMAFA_ZONE(2, 3, 1) SMAFA_ZONE(3, 3, 1) SMAFA_ZONE(5, 5, 1) SMAFA_ZONE(2, 3, 2) SMAFA_ZONE(3, 3, 2) SMAFA_ZONE(5, 5, 2)
+        SMAFA_ZONE(2, 3, 3) SMAFA_ZONE(3, 3, 3) SMAFA_ZONE(5, 5, 3) SMAFA_ZONE(2, 3, 4) SMAFA_ZONE(3, 3, 4) SMAFA_ZONE(5, 5, 4)
+#undef SMAFA_ZONE
     }
     if (lazy) {  // filter-plane-resident kernel
 #define SMAFA_LAZY(PS_, PQ_, W_, T_)                                  \
@@ -350,15 +569,20 @@ static uint32_t choose_query_block(const smafa_db *db, uint32_t n_wg_tiles, uint
     return std::max(qb, 1u);
 }
 
-// one kernel launch: queries [q_begin, q_end) x wave tiles [tile_begin, tile_end)
+// one kernel launch: queries [q_begin, q_end) x wave tiles [tile_begin, tile_end).  Rows go to `d_rows` (room for
+// `rows_cap`) through the handle's counter; publish != NULL: the launch is the whole scan — its last workgroup writes the
+// row total to *publish and leaves the counters at zero.
 static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t tile_begin,
-                        uint32_t tile_end, uint32_t k_tight, uint32_t thr0, smafa_hit *d_shards, uint64_t shard_cap,
-                        unsigned long long *d_shard_counts, bool per_query_bounds = false) {
+                        uint32_t tile_end, uint32_t k_tight, uint32_t thr0, smafa_hit *d_rows, uint64_t rows_cap,
+                        unsigned long long *publish, bool per_query_bounds = false) {
     ScanArgs a;
     const bool specialised = db->W <= 4;  // else scan_wide_kernel / scan_generic_kernel
     const bool wide = use_wide(db, thr0);
     const bool lazy = wide || (specialised && use_lazy(db, thr0));
-    const uint32_t T = wide ? (uint32_t)kWideTiles : specialised ? tiles_per_wave(db, lazy) : (uint32_t)kGenericTiles;
+    const bool seed = d_rows == nullptr && k_tight == 1;  // the seed pass covers a few tiles: no zone level
+    const bool zone = lazy && !wide && !seed && use_zone(db, thr0);
+    const uint32_t T = zone ? (uint32_t)kZoneTiles
+                     : wide ? (uint32_t)kWideTiles : specialised ? tiles_per_wave(db, lazy) : (uint32_t)kGenericTiles;
     a.tile_begin = tile_begin;
     a.tile_end = tile_end;
     a.n_wg_tiles = (tile_end - tile_begin + kWgWaves * T - 1) / (kWgWaves * T);
@@ -373,14 +597,18 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     a.cnt_stride = db->L + 1;
     a.k_tight = k_tight;
     a.use_filter = db->use_filter ? 1u : 0u;
-    a.hits = d_shards;
-    a.shard_cap = shard_cap;
-    a.count = d_shard_counts;
+    a.hits = d_rows;
+    a.cap = rows_cap;
+    a.count = db->ctrs.as<unsigned long long>();
+    a.done = publish ? reinterpret_cast<uint32_t *>(db->ctrs.as<uint8_t>() + 256) : nullptr;
+    a.publish = publish;
+    a.order = db->d_order;
+    a.zone = db->d_zone;
     const uint64_t n_qblocks = (q_end - q_begin + a.qb_size - 1) / a.qb_size;
     const uint64_t grid = n_qblocks * a.n_wg_tiles;
     if (grid > 0x7fffffffull)
         return set_error(SMAFA_ERR_INVALID, "scan grid too large (%llu workgroups)", (unsigned long long)grid);
-    launch_scan(db, qs->qrec.as<uint32_t>(), a, (uint32_t)grid, T, lazy);
+    launch_scan(db, qs->qrec.as<uint32_t>(), a, (uint32_t)grid, T, lazy, zone);
     db->plan_lazy = lazy ? 1u : 0u;
     db->plan_tiles = T;
     db->plan_qblocks = (uint32_t)n_qblocks;
@@ -390,11 +618,14 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
 }
 
 // Scan queries [q_begin, q_end) of a resident set against the whole store; rows and their count stay on
-// the device.  k_tight = 0: one launch, fixed bound max_div.  k_tight >= 1: the bound of each query is
-// lowered to its running k-th smallest distance while the scan proceeds.  Workgroups of one launch run
-// side by side and would all start from the loose initial bound, so the store is walked in segments that
-// grow 8x per launch (bounds tighten between launches), after a seed launch over the first segment that
-// only lowers the bounds and appends nothing.
+// the device.
+// k_tight = 0: ONE launch, fixed bound max_div: the kernel appends straight into the caller's list and its last
+// workgroup publishes the total in *d_count (which may exceed cap: the rows past it are dropped, the count is exact).
+// k_tight >= 1: the bound of each query is lowered to its running k-th smallest distance while the scan proceeds.
+// Workgroups of one launch run side by side and would all start from the loose initial bound, so the store is walked
+// in segments that grow 8x per launch (bounds tighten between launches), after a seed launch over the first segment
+// that only lowers the bounds and appends nothing.  Rows are appended to a scratch list while the bounds are still
+// running; filter_rows_kernel then keeps the ones within the final bounds.
 static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t max_div,
                       uint32_t k_tight, smafa_hit *d_hits, uint64_t cap, unsigned long long *d_count) {
     const uint32_t nq = q_end - q_begin;
@@ -404,27 +635,32 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
         HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), db->stream));
         return SMAFA_OK;
     }
-    // the kernels append into kShards segments of a scratch block (twice the caller's capacity, so that an uneven
-    // spread over the segments does not look like an overflow); compact_rows_kernel gathers them at the end
-    // Tightening modes append every pair that is within its query's bound at that moment — 50-100 rows per query
-    // when the bound starts loose — of which the gather keeps the ones within the final bound: the scratch block is
-    // sized for the appended volume, the caller's buffer only has to hold what is kept.
-    uint64_t scratch_rows = 2 * cap;
-    const uint32_t thr0_ = std::min<uint32_t>(max_div, db->L);
-    // (k >= 2 with a loose bound counts first and appends only the final rows: k per query plus ties)
-    const uint64_t per_query = (k_tight >= db->count_first_k && !prefilter_prunes(db, thr0_)) ? (uint64_t)k_tight + 64u : 128u;
-    if (k_tight) scratch_rows = std::max<uint64_t>(scratch_rows, std::min<uint64_t>((uint64_t)nq * per_query, 1ull << 27));
-    const uint64_t shard_cap = (scratch_rows + kShards - 1) / kShards + 256;
-    int src = db->shard_rows.ensure(shard_cap * kShards * sizeof(smafa_hit));
-    if (!src) src = db->shard_counts.ensure((size_t)kShards * kCountStride * sizeof(unsigned long long));
-    if (src) return src;
-    smafa_hit *d_shards = db->shard_rows.as<smafa_hit>();
-    unsigned long long *d_shard_counts = db->shard_counts.as<unsigned long long>();
-    HIP_TRY(hipMemsetAsync(d_shard_counts, 0, (size_t)kShards * kCountStride * sizeof(unsigned long long), db->stream));
+    unsigned long long *d_ctr = db->ctrs.as<unsigned long long>();
     const uint32_t thr0 = std::min<uint32_t>(max_div, db->L);  // a distance never exceeds seq_len
-    if (k_tight)
-        hipLaunchKernelGGL(fill_u32_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream,
-                           qs->thr.as<uint32_t>() + q_begin, thr0, (uint64_t)nq);
+    const uint32_t n_tiles = (uint32_t)((db->n + kWaveTile - 1) / kWaveTile);
+    if (k_tight == 0) {
+        HIP_TRY(hipEventRecord(db->ev0, db->stream));
+        int rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, thr0, d_hits, cap, d_count);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(db->ev1, db->stream));
+        db->timed = true;
+        return SMAFA_OK;
+    }
+    // Tightening modes append every pair that is within its query's bound at that moment — 50-100 rows per query
+    // when the bound starts loose — of which the filter pass keeps the ones within the final bound: the scratch list
+    // is sized for the appended volume, the caller's buffer only has to hold what is kept.
+    // (k >= 2 with a loose bound counts first and appends only the final rows, straight into the caller's list.)
+    const bool count_first = k_tight >= db->count_first_k && !prefilter_prunes(db, thr0);
+    uint64_t scratch_rows = 0;
+    if (!count_first) {
+        scratch_rows = std::max<uint64_t>(2 * cap, std::min<uint64_t>((uint64_t)nq * 128u, 1ull << 27));
+        int src = db->scratch.ensure(scratch_rows * sizeof(smafa_hit));
+        if (src) return src;
+    }
+    smafa_hit *d_scratch = db->scratch.as<smafa_hit>();
+    HIP_TRY(hipMemsetAsync(d_ctr, 0, sizeof(unsigned long long), db->stream));
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream, qs->thr.as<uint32_t>() + q_begin,
+                       thr0, (uint64_t)nq);
     const size_t cnt_stride = db->L + 1;
     auto zero_cnt = [&]() -> int {
         if (k_tight < 2) return SMAFA_OK;
@@ -434,45 +670,43 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
                                (size_t)nq * cnt_stride * sizeof(uint32_t), db->stream));
         return SMAFA_OK;
     };
-    const uint32_t n_tiles = (uint32_t)((db->n + kWaveTile - 1) / kWaveTile);
     HIP_TRY(hipEventRecord(db->ev0, db->stream));
-    int rc = SMAFA_OK;
-    if (k_tight == 0) {
-        rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, thr0, d_shards, shard_cap, d_shard_counts);
-    } else {
-        rc = zero_cnt();
-        // seed: k = 1 reduces each wave's minimum before its single atomicMin, so a whole workgroup tile is
-        // cheap; the k >= 2 seed counts every pair in its histogram, so keep it to one wave tile
-        const uint32_t seed_tiles = std::min<uint32_t>(k_tight == 1 ? kWgWaves : 1, n_tiles);
-        if (!rc) rc = launch_tiles(db, qs, q_begin, q_end, 0, seed_tiles, k_tight, thr0, nullptr, 0, d_shard_counts);
-        if (!rc) rc = zero_cnt();  // the seed's subjects are counted again below
-        // k >= 2 with a bound the prefilter cannot use: a query appends every pair within its running k-th bound,
-        // thousands of rows for k = 50 against unrelated subjects.  Two passes instead: the first only counts
-        // (cnt[q][dist]) and tightens, which yields the EXACT k-th distance of every query
-        // (kth_from_counts_kernel); the second appends with those bounds fixed — exactly the rows that are kept.
-        const bool count_first = k_tight >= db->count_first_k && !prefilter_prunes(db, thr0);
-        uint32_t begin = 0, len = kWgWaves;
-        while (!rc && begin < n_tiles) {
-            const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)begin + len, n_tiles);
-            rc = launch_tiles(db, qs, q_begin, q_end, begin, end, k_tight, thr0, count_first ? nullptr : d_shards,
-                              count_first ? 0 : shard_cap, d_shard_counts);
-            begin = end;
-            len = len > (1u << 28) ? len : len * 8;
-        }
-        if (!rc && count_first) {
-            hipLaunchKernelGGL(kth_from_counts_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream,
-                               qs->cnt.as<uint32_t>(), (uint32_t)cnt_stride, k_tight, qs->thr.as<uint32_t>(), q_begin, nq);
-            rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, thr0, d_shards, shard_cap, d_shard_counts, true);
-        }
+    int rc = zero_cnt();
+    // seed: k = 1 reduces each wave's minimum before its single atomicMin, so a whole workgroup tile is
+    // cheap; the k >= 2 seed counts every pair in its histogram, so keep it to one wave tile
+    const uint32_t seed_tiles = std::min<uint32_t>(k_tight == 1 ? kWgWaves : 1, n_tiles);
+    if (!rc) rc = launch_tiles(db, qs, q_begin, q_end, 0, seed_tiles, k_tight, thr0, nullptr, 0, nullptr);
+    if (!rc) rc = zero_cnt();  // the seed's subjects are counted again below
+    // k >= 2 with a bound the prefilter cannot use: a query appends every pair within its running k-th bound,
+    // thousands of rows for k = 50 against unrelated subjects.  Two passes instead: the first only counts
+    // (cnt[q][dist]) and tightens, which yields the EXACT k-th distance of every query
+    // (kth_from_counts_kernel); the second appends with those bounds fixed — exactly the rows that are kept.
+    uint32_t begin = 0, len = kWgWaves;
+    while (!rc && begin < n_tiles) {
+        const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)begin + len, n_tiles);
+        rc = launch_tiles(db, qs, q_begin, q_end, begin, end, k_tight, thr0, count_first ? nullptr : d_scratch,
+                          count_first ? 0 : scratch_rows, nullptr);
+        begin = end;
+        len = len > (1u << 28) ? len : len * 8;
     }
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(db->ev1, db->stream));  // smafa_last_scan_ms: the scan kernels, not the gather below
+    if (count_first) {
+        hipLaunchKernelGGL(kth_from_counts_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream, qs->cnt.as<uint32_t>(),
+                           (uint32_t)cnt_stride, k_tight, qs->thr.as<uint32_t>(), q_begin, nq);
+        rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, thr0, d_hits, cap, d_count, true);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(db->ev1, db->stream));
+        db->timed = true;
+        return SMAFA_OK;
+    }
+    HIP_TRY(hipEventRecord(db->ev1, db->stream));  // smafa_last_scan_ms: the scan kernels, not the filter pass below
     db->timed = true;
-    const uint32_t *final_thr = k_tight ? qs->thr.as<uint32_t>() : nullptr;
-    if (final_thr) HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), db->stream));
-    hipLaunchKernelGGL(compact_rows_kernel, dim3(kShards), dim3(256), 0, db->stream, d_shards, d_shard_counts,
-                       (unsigned long long)shard_cap, d_hits, (unsigned long long)cap, d_count, final_thr);
+    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), db->stream));
+    hipLaunchKernelGGL(filter_rows_kernel, dim3((uint32_t)std::min<uint64_t>(1024, (scratch_rows + 255) / 256)), dim3(256), 0,
+                       db->stream, d_scratch, d_ctr, (unsigned long long)scratch_rows, d_hits, (unsigned long long)cap,
+                       d_count, qs->thr.as<uint32_t>());
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(d_ctr, 0, sizeof(unsigned long long), db->stream));  // counters are zero between scans
     return SMAFA_OK;
 }
 
@@ -590,6 +824,12 @@ static int collect_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_
         done = count <= db->hits_cap();
     }
     if (!done) {
+        // a fixed-bound scan reports its exact total: make room for it and scan once more (up to 128M rows = 1.5 GB)
+        if (!k_tight && count <= (1ull << 27)) {
+            int rc = db->hits.ensure(count * sizeof(smafa_hit));
+            if (rc) return rc;
+            return collect_range(db, qs, q_begin, q_end, max_div, max_num_hits, out);
+        }
         if (q_end - q_begin > 1) {
             const uint32_t mid = q_begin + (q_end - q_begin) / 2;
             int rc = collect_range(db, qs, q_begin, mid, max_div, max_num_hits, out);
@@ -616,6 +856,7 @@ void warm_device(int device) {
 int db_clear(smafa_db *db) {
     if (!db) return set_error(SMAFA_ERR_INVALID, "db_clear: NULL handle");
     db->n = 0;
+    db->runs.clear();
     db->generation++;
     return SMAFA_OK;
 }
@@ -712,6 +953,13 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
         }
         out.resize(w);
     }
+    // scratch of an unusually large answer is not worth keeping (the buffers regrow on demand)
+    if (db->scratch.cap > (512ull << 20)) db->scratch.release();
+    if (db->keys_a.cap > (512ull << 20)) {
+        db->keys_a.release();
+        db->keys_b.release();
+        db->sort_tmp.release();
+    }
     return SMAFA_OK;
 }
 
@@ -759,14 +1007,18 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     if (const char *cv = getenv("SMAFA_COUNT_FIRST_K")) db->count_first_k = (uint32_t)std::max(2, atoi(cv));
     if (const char *ov = getenv("SMAFA_WIDE_ONE")) db->wide_one = atoi(ov) != 0;
     if (const char *wv = getenv("SMAFA_WIDE_FROM")) db->wide_from = (uint32_t)std::max(3, atoi(wv));
+    if (const char *zv = getenv("SMAFA_ZONE")) db->zone = std::min(2, std::max(0, atoi(zv)));
+    if (const char *sv = getenv("SMAFA_SORT")) db->sort_rows = atoi(sv) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) db->n_cu = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&db->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&db->ev0);
     if (e == hipSuccess) e = hipEventCreate(&db->ev1);
+    if (e == hipSuccess && db->ctrs.ensure(kCtrBytes) != SMAFA_OK) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMemset(db->ctrs.p, 0, kCtrBytes);  // the scan kernels leave their counters at zero
     if (e != hipSuccess) {
         smafa_db_destroy(db);
-        return set_error(SMAFA_ERR_DEVICE, "stream/event creation failed: %s", hipGetErrorString(e));
+        return set_error(SMAFA_ERR_DEVICE, "stream/event/counter creation failed: %s", hipGetErrorString(e));
     }
     db->stream = db->own_stream;
     *out = db;
@@ -792,7 +1044,9 @@ int smafa_db_append(smafa_db *db, const uint8_t *codes, uint64_t n) {
     if (rc) return rc;
     db->n += n;
     db->generation++;
-    if (n > (1u << 20)) db->upload.release();  // a bulk load's staging buffer is not worth keeping
+    if (n > (1u << 20)) {  // a bulk load's staging and sort buffers are not worth keeping
+        for (DevBuf *b : {&db->upload, &db->keys_a, &db->keys_b, &db->idx_a, &db->idx_b, &db->sort_tmp}) b->release();
+    }
     return SMAFA_OK;
 }
 
@@ -819,7 +1073,10 @@ void smafa_db_destroy(smafa_db *db) {
     if (!db) return;
     (void)hipSetDevice(db->device);
     if (db->d_planes) (void)hipFree(db->d_planes);
-    for (DevBuf *b : {&db->upload, &db->hits, &db->count, &db->shard_rows, &db->shard_counts, &db->keys_a, &db->keys_b, &db->sort_tmp, &db->scratch_q.qrec,
+    if (db->d_order) (void)hipFree(db->d_order);
+    if (db->d_zone) (void)hipFree(db->d_zone);
+    for (DevBuf *b : {&db->upload, &db->hits, &db->count, &db->scratch, &db->ctrs, &db->keys_a, &db->keys_b, &db->sort_tmp,
+                      &db->idx_a, &db->idx_b, &db->d_perm, &db->d_tab, &db->scratch_q.qrec,
                       &db->scratch_q.thr, &db->scratch_q.cnt, &db->scratch_q2.qrec, &db->scratch_q2.thr, &db->scratch_q2.cnt})
         b->release();
     if (db->ev0) (void)hipEventDestroy(db->ev0);
@@ -1017,8 +1274,8 @@ int smafa_distances(smafa_db *db, const uint8_t *query_codes, uint32_t *distance
     rc = db->keys_a.ensure((size_t)n_tiles * kWaveTile * sizeof(uint32_t));  // any scratch buffer will do
     if (rc) return rc;
     hipLaunchKernelGGL(distances_kernel, dim3((n_tiles + kWgWaves - 1) / kWgWaves), dim3(256), 0, db->stream,
-                       reinterpret_cast<const uint4 *>(db->d_planes), n_tiles, db->P, db->PQ, db->W,
-                       db->scratch_q.qrec.as<uint32_t>(), db->keys_a.as<uint4>());
+                       reinterpret_cast<const uint4 *>(db->d_planes), n_tiles, (uint32_t)db->n, db->P, db->PQ, db->W,
+                       db->scratch_q.qrec.as<uint32_t>(), db->d_order, db->keys_a.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(distances, db->keys_a.p, db->n * sizeof(uint32_t), hipMemcpyDeviceToHost, db->stream));
     HIP_TRY(hipStreamSynchronize(db->stream));

@@ -45,9 +45,7 @@ namespace smafa {
 constexpr int kWaveTile = 256;  // subjects per wave tile
 constexpr int kWgWaves = 4;     // waves per workgroup
 constexpr int kChunk = 64;      // queries staged in LDS at a time
-constexpr uint32_t kShards = 64;  // row-append segments (and counters) per scan
-constexpr uint32_t kCountStride = 32;  // u64 slots between two shard counters: one counter per 256 B, so that atomics
-                                       // on different shards do not queue up behind each other on one cache line
+constexpr int kStageRows = 256;  // rows a workgroup parks in LDS (per chunk parity) before ONE reservation in the row list
 // __launch_bounds__ second argument (waves per SIMD the register budget must allow) for the scan kernel:
 // the subject words held per lane plus ~40 working registers, mapped through the gfx950 allocation steps.
 __host__ __device__ constexpr int scan_min_waves(int ps, int w, int t) {
@@ -64,9 +62,12 @@ __host__ __device__ constexpr int scan_min_waves(int ps, int w, int t) {
 __host__ __device__ constexpr int round_up4(int x) { return (x + 3) & ~3; }
 // query record stride in u32 words: the plane words plus the bound slot, rounded up to whole uint4s
 __host__ __device__ constexpr int qrec_stride(int planes, int words) { return round_up4(planes * words + 1); }
-// The plane the prefilter looks at.  Nucleotide codes are A=0 C=1 G=2 T=3 N=4: bit 1 separates {A,C} from
-// {G,T}, so it sees both transitions (A<->G, C<->T), the commonest real substitutions; bit 0 would miss them.
-__host__ __device__ constexpr int filter_plane(int planes) { return planes == 3 ? 1 : 0; }
+// The plane the prefilter looks at: always plane 0.  Codes are re-coded PER COLUMN when a store is laid out (the
+// distance only depends on equality of codes within a column, so any per-column injective map keeps every result):
+// bit 0 of the re-coded symbol splits the column's letters into two sets of nearly equal total frequency, which makes
+// a mismatch flip the filter bit as often as the column allows (host: choose_layout() in engine.hip).  Without
+// statistics the nucleotide map is A=0 C=2 G=1 T=3 N=4: bit 0 separates {A,C} from {G,T}, so it sees both transitions.
+__host__ __device__ constexpr int filter_plane(int) { return 0; }
 // slot of word w of plane p inside a record
 // The bound sits right after the first two filter words, so the first uint4 of a record holds everything
 // levels 1 and 2 of scan_wide_kernel need: [f0 f1 bound f2 f3 ... | other planes] ([f0 bound] for one word).
@@ -88,12 +89,27 @@ struct ScanArgs {
     uint32_t cnt_stride;
     uint32_t k_tight;         // 0: bounds fixed; 1: lower to running minimum; k>=2: lower to running k-th
     uint32_t use_filter;      // 0: always the full comparison; 1: prefilter with per-wave fallback
-    // Row append, sharded: workgroup b appends to segment b % kShards of `hits` (shard_cap rows each) through
-    // counter count[b % kShards] — one global counter saturates near 80 M appends/s, which is what a dense scan
-    // needs per millisecond.  compact_rows_kernel then restores one contiguous list + one count.
-    smafa_hit *hits;          // NULL: seed pass — tighten bounds, append nothing
-    unsigned long long shard_cap;
-    unsigned long long *count;  // kShards counters
+    // Row append: ONE list, ONE counter.  A workgroup parks its rows in LDS (RowStage) and reserves room in the list
+    // once per 64-query chunk, so a dense scan costs the counter one atomic per workgroup and chunk instead of one per
+    // wave and row group (one counter saturates near 80 M atomics/s; a dense scan appends > 1 G rows/s).
+    smafa_hit *hits;            // NULL: seed / counting pass — tighten bounds, append nothing
+    unsigned long long cap;     // rows `hits` can hold; rows past it are dropped, the counter keeps counting
+    unsigned long long *count;  // rows appended so far
+    // done != NULL: the last workgroup to finish publishes the total in *publish and zeroes count and done again —
+    // a fixed-bound scan is then ONE launch: no counter reset before it, no gather after it
+    uint32_t *done;
+    unsigned long long *publish;
+    const uint32_t *order;      // position in the packed store -> subject index (the order subjects were appended in)
+    const uint4 *zone;          // per wave tile: {bits all its subjects share in filter word 0, which bits those are,
+                                //                 the same for word 1} — see zone_kernel
+};
+
+// Where a workgroup parks qualifying rows between two flushes: one buffer per chunk parity, so that the rows of
+// chunk k are written out while chunk k+1 already appends to the other buffer (no extra barrier on the common path).
+struct RowStage {
+    smafa_hit rows[2][kStageRows];
+    uint32_t n[2];            // rows parked (may run past kStageRows: the excess went straight to the list)
+    unsigned long long base;  // the flushing thread's reservation, read by the whole workgroup
 };
 
 // acc | (s ^ q) in one VALU op.  Truth table over (a=0xF0, b=0xCC, c=0xAA): 0xF0 | (0xCC ^ 0xAA) = 0xF6.
@@ -117,30 +133,40 @@ __device__ __forceinline__ uint32_t ld_relaxed(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Rare path: append one qualifying pair and, when asked, tighten the query's bound.
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
+    return ((unsigned long long)(uint32_t)__shfl((int)(v >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(v & 0xffffffffull), src, 64);
+}
+
+// Rare path: append one qualifying pair and, when asked, tighten the query's bound.  `pos` is the subject's position
+// in the packed store; the row carries its subject index (a.order).
 // Correctness of tightening: thr[q] is only lowered to a distance d once at least k subjects with
 // distance <= d have been counted, so thr[q] >= (k-th smallest distance of q) at all times and every
 // subject within the true bound passes `dist <= thr` whenever it is visited.
-__device__ __forceinline__ void emit(const ScanArgs &a, uint32_t q, uint32_t subject, uint32_t dist) {
+__device__ __forceinline__ void emit(const ScanArgs &a, RowStage &rs, int parity, uint32_t q, uint32_t pos, uint32_t dist) {
     if (a.hits) {
-        // One atomic per wave, not per row: the lanes that got here together (a wave works on one query at a
-        // time, so they all append for the same query) take consecutive slots.  (What limited dense scans was
-        // not the number of atomics but counters sharing cache lines — see kCountStride.)
+        // The lanes that got here together (a wave works on one query at a time, so they all append for the same
+        // query) take consecutive slots of the workgroup's LDS stage: one LDS atomic per wave (v_mbcnt ranks the lanes).
+        smafa_hit h;
+        h.query = q;
+        h.subject = a.order[pos];
+        h.dist = dist;
         const unsigned long long together = __ballot(1);  // the active lanes
         const uint32_t lane = __lane_id();
         const int leader = __builtin_ctzll(together);
-        const uint32_t shard = blockIdx.x % kShards;
-        unsigned long long base = 0;
-        if ((int)lane == leader) base = atomicAdd(a.count + (size_t)shard * kCountStride, (unsigned long long)__builtin_popcountll(together));
-        base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), leader, 64) << 32) |
-               (uint32_t)__shfl((int)(base & 0xffffffffull), leader, 64);
-        const unsigned long long slot = base + lanes_below(together);  // v_mbcnt: set bits of `together` below this lane
-        if (slot < a.shard_cap) {
-            smafa_hit h;
-            h.query = q;
-            h.subject = subject;
-            h.dist = dist;
-            a.hits[(size_t)shard * a.shard_cap + slot] = h;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&rs.n[parity], (uint32_t)__builtin_popcountll(together));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        const uint32_t slot = base + lanes_below(together);
+        if (slot < (uint32_t)kStageRows) {
+            rs.rows[parity][slot] = h;
+        } else {
+            // the stage is full until the next flush (a dense neighbourhood): straight to the list, one atomic per wave
+            const unsigned long long spill = __ballot(1);
+            const int first = __builtin_ctzll(spill);
+            unsigned long long g = 0;
+            if ((int)lane == first) g = atomicAdd(a.count, (unsigned long long)__builtin_popcountll(spill));
+            g = shfl_u64(g, first) + lanes_below(spill);
+            if (g < a.cap) a.hits[g] = h;
         }
     }
     if (a.k_tight == 1) {
@@ -152,6 +178,51 @@ __device__ __forceinline__ void emit(const ScanArgs &a, uint32_t q, uint32_t sub
         uint32_t seen = 0;
         for (uint32_t t = 0; t <= dist; t++) seen += ld_relaxed(c + t);
         if (seen >= a.k_tight) atomicMin(a.thr + q, dist);
+    }
+}
+
+// Write the rows parked under `parity` out to the list.  Called by EVERY thread of the workgroup right after the
+// barrier that ends a chunk: nobody appends to this parity again before the next chunk's barrier, so n is stable and
+// the branch is uniform.
+__device__ __forceinline__ void flush_rows(const ScanArgs &a, RowStage &rs, int parity) {
+    const uint32_t parked = rs.n[parity];
+    if (parked == 0) return;
+    const uint32_t n = min(parked, (uint32_t)kStageRows);
+    if (threadIdx.x == 0) rs.base = atomicAdd(a.count, (unsigned long long)n);
+    __syncthreads();
+    const unsigned long long base = rs.base;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+        if (base + i < a.cap) a.hits[base + i] = rs.rows[parity][i];
+    if (threadIdx.x == 0) rs.n[parity] = 0;  // every thread read it before the barrier above
+}
+
+// End of a scan kernel, every thread: (optionally) publish the total.  The workgroup whose ticket is the last one
+// reads the counter after every other workgroup's reservations: a reservation is an atomic that has RETURNED (the
+// thread used its value) before that workgroup's ticket is taken — by the same thread, or by another thread of the
+// workgroup ahead of the barrier below — and device-scope atomics are performed at the device's coherence point, so
+// no fence is needed (a __threadfence() here writes the XCD's L2 back once per workgroup: it cost 6x on a one-query
+// pass).  The last workgroup also resets both counters, so the next launch on the stream starts from zero without a
+// memset.  Row data are plain stores, visible to the stream's next operation like any kernel output.
+// Tickets are taken in two levels:
+constexpr uint32_t kTicketGroups = 64;   // first-level ticket counters (one atomic address takes ~80 M tickets/s:
+constexpr uint32_t kTicketStride = 32;   // 2 442 workgroups of a one-query pass would queue for 30 us on a single one)
+// `done` = u32 array: [0] second-level tickets, [kTicketStride * (1 + g)] tickets of group g — every counter on its own
+// 128-byte line.  Workgroup b belongs to group b % kTicketGroups.
+__device__ __forceinline__ void finish_rows(const ScanArgs &a) {
+    if (a.done == nullptr) return;
+    __syncthreads();  // this workgroup's reservations (flushes and spills) have all returned
+    if (threadIdx.x == 0) {
+        const uint32_t groups = min(kTicketGroups, gridDim.x);
+        const uint32_t g = blockIdx.x % kTicketGroups;
+        const uint32_t members = (gridDim.x - g + kTicketGroups - 1) / kTicketGroups;  // workgroups with this remainder
+        uint32_t *mine = a.done + kTicketStride * (1 + g);
+        if (atomicAdd(mine, 1u) == members - 1) {  // last of its group
+            atomicExch(mine, 0u);
+            if (atomicAdd(a.done, 1u) == groups - 1) {  // last group: every reservation of the launch has returned
+                *a.publish = atomicExch(a.count, 0ull);
+                atomicExch(a.done, 0u);
+            }
+        }
     }
 }
 
@@ -193,8 +264,11 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
     // with a single word the bound is taken per subject
     constexpr bool kPair = SMAFA_AND_PAIR && W > 1;
     __shared__ uint4 stage[2][kChunk * RV];
+    __shared__ RowStage rs;
+    int buf = 0;  // LDS buffer of the chunk being computed = parity of the row stage it appends to
 
     const uint32_t tid = threadIdx.x;
+    if (tid == 0) rs.n[0] = rs.n[1] = 0;  // published by the barrier in front of the chunk loop
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
     const uint32_t wg_tile = blockIdx.x % a.n_wg_tiles;  // tiles fastest: all CUs share one query block
@@ -279,7 +353,7 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
                 if (SEED) {
                     if (real) lo = min(lo, d[k]);
                 } else if (real && d[k] <= U) {
-                    emit(a, q, subj0 + k, d[k]);
+                    emit(a, rs, buf, q, subj0 + k, d[k]);
                 }
             }
         }
@@ -307,7 +381,6 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
         commit(0, q0);
     }
     __syncthreads();
-    int buf = 0;
     bool filter_on = a.use_filter != 0;
     bool level1_on = true;
     uint32_t chunk_no = 0;
@@ -392,7 +465,9 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
         }
         if (more) commit(buf ^ 1, qc + kChunk);
         __syncthreads();
+        if (!SEED && a.hits) flush_rows(a, rs, buf);
     }
+    if (!SEED) finish_rows(a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -427,28 +502,31 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
     constexpr int HV = (W + 1 + 3) / 4;
     constexpr bool kPair = SMAFA_AND_PAIR && W > 1;  // see scan_kernel
     __shared__ uint4 stage[2][kChunk * RV];
+    __shared__ RowStage rs;
+    int buf = 0;  // LDS buffer of the chunk being computed = parity of the row stage it appends to
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
+    if (tid == 0) rs.n[0] = rs.n[1] = 0;  // published by the barrier in front of the chunk loop
     const uint32_t wg_tile = blockIdx.x % a.n_wg_tiles;
     const uint32_t qblock = blockIdx.x / a.n_wg_tiles;
     const uint32_t tile0 = a.tile_begin + (wg_tile * kWgWaves + wave) * T;
     const bool active = tile0 < a.tile_end;
+    const uint32_t q0 = a.q_begin + qblock * a.qb_size;
+    const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
 
     // filter-plane words of this lane's 4*T subjects; tile slots past the range hold a copy of tile_begin
     // (valid memory) and are ignored wherever rows could come out of them
     uint4 f[T][W];
-#pragma unroll
-    for (int t = 0; t < T; t++) {
+    auto load_filter = [&](int t) {
         const bool live = tile0 + t < a.tile_end;
         const uint4 *src = planes + (size_t)(live ? tile0 + t : a.tile_begin) * (PS * W * 64) + lane;
 #pragma unroll
         for (int w = 0; w < W; w++) f[t][w] = src[(FP * W + w) * 64];
-    }
-    const uint32_t q0 = a.q_begin + qblock * a.qb_size;
-    const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
-
+    };
+#pragma unroll
+    for (int t = 0; t < T; t++) load_filter(t);
     uint4 pre[NV];
     auto fetch = [&](uint32_t qc) {
         const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
@@ -469,12 +547,12 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
             }
         }
     };
-    auto commit = [&](int buf, uint32_t qc) {
+    auto commit = [&](int b, uint32_t qc) {
         const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
 #pragma unroll
         for (int v = 0; v < NV; v++) {
             const uint32_t idx = tid + v * 256;
-            if (idx < nqc * RV) stage[buf][idx] = pre[v];
+            if (idx < nqc * RV) stage[b][idx] = pre[v];
         }
     };
     auto read_record = [&](const uint4 *rec, uint32_t(&qw)[RS], int from, int to) {
@@ -529,7 +607,19 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, q, subj0 + k, d[k]);
+                if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, rs, buf, q, subj0 + k, d[k]);
+        }
+    };
+    // the filter plane of tile slot t folded over its words against the record's filter words
+    auto fold = [&](int t, const uint32_t(&qw)[RS], uint32_t &m0, uint32_t &m1, uint32_t &m2, uint32_t &m3) {
+        m0 = f[t][0].x ^ qw[0], m1 = f[t][0].y ^ qw[0];
+        m2 = f[t][0].z ^ qw[0], m3 = f[t][0].w ^ qw[0];
+#pragma unroll
+        for (int w = 1; w < W; w++) {
+            m0 = or_xor(m0, f[t][w].x, qw[qslot(PQ, W, FP, w)]);
+            m1 = or_xor(m1, f[t][w].y, qw[qslot(PQ, W, FP, w)]);
+            m2 = or_xor(m2, f[t][w].z, qw[qslot(PQ, W, FP, w)]);
+            m3 = or_xor(m3, f[t][w].w, qw[qslot(PQ, W, FP, w)]);
         }
     };
 
@@ -538,7 +628,6 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
         commit(0, q0);
     }
     __syncthreads();
-    int buf = 0;
     bool filter_on = a.use_filter != 0;
     bool level1_on = true;
     uint32_t chunk_no = 0;
@@ -576,15 +665,8 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
                         uint32_t tsign[T];
 #pragma unroll
                         for (int t = 0; t < T; t++) {
-                            uint32_t m0 = f[t][0].x ^ qw[0], m1 = f[t][0].y ^ qw[0];
-                            uint32_t m2 = f[t][0].z ^ qw[0], m3 = f[t][0].w ^ qw[0];
-#pragma unroll
-                            for (int w = 1; w < W; w++) {
-                                m0 = or_xor(m0, f[t][w].x, qw[qslot(PQ, W, FP, w)]);
-                                m1 = or_xor(m1, f[t][w].y, qw[qslot(PQ, W, FP, w)]);
-                                m2 = or_xor(m2, f[t][w].z, qw[qslot(PQ, W, FP, w)]);
-                                m3 = or_xor(m3, f[t][w].w, qw[qslot(PQ, W, FP, w)]);
-                            }
+                            uint32_t m0, m1, m2, m3;
+                            fold(t, qw, m0, m1, m2, m3);
                             tsign[t] = kPair ? ((__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu))
                                              : (or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
                                                     __builtin_popcount(m2) + nu) |
@@ -606,15 +688,8 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
 #pragma unroll
                                 for (int t = 0; t < T; t++) {
                                     if ((live >> t) & 1u) {
-                                        uint32_t m0 = f[t][0].x ^ qw[0], m1 = f[t][0].y ^ qw[0];
-                                        uint32_t m2 = f[t][0].z ^ qw[0], m3 = f[t][0].w ^ qw[0];
-#pragma unroll
-                                        for (int w = 1; w < W; w++) {
-                                            m0 = or_xor(m0, f[t][w].x, qw[qslot(PQ, W, FP, w)]);
-                                            m1 = or_xor(m1, f[t][w].y, qw[qslot(PQ, W, FP, w)]);
-                                            m2 = or_xor(m2, f[t][w].z, qw[qslot(PQ, W, FP, w)]);
-                                            m3 = or_xor(m3, f[t][w].w, qw[qslot(PQ, W, FP, w)]);
-                                        }
+                                        uint32_t m0, m1, m2, m3;
+                                        fold(t, qw, m0, m1, m2, m3);
                                         const uint32_t each = or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
                                                                   __builtin_popcount(m2) + nu) |
                                                               (__builtin_popcount(m3) + nu);
@@ -654,7 +729,408 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
         }
         if (more) commit(buf ^ 1, qc + kChunk);
         __syncthreads();
+        if (!SEED && a.hits) flush_rows(a, rs, buf);
     }
+    if (!SEED) finish_rows(a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The scan of a SORTED store: zone level in front of levels 1-3.
+//
+// Big appends are sorted by their filter words when they are laid out (pack_rows in engine.hip), so the 256 subjects of
+// a wave tile share their leading filter bits, and zone[tile] = {those bits, which bits they are} for filter words 0
+// and 1 (zone_kernel).  For a query, popcount((Q_f ^ common) & shared) counts columns in which EVERY subject of the
+// tile mismatches: a lower bound on all 256 distances at once.  The wave evaluates it for 64 queries at a time — lane i
+// takes query i of the chunk, ~6 VALU ops per (64 queries x tile) — and only the (query, tile) pairs that survive enter
+// level 1, one query at a time, the query's word and bound broadcast out of lane i by v_readlane.  On a 10M-row store
+// a tile shares ~15 bits: at bound 5 about 1 pair in 6 survives, at bound 3 about 1 in 50.
+// A lane keeps ONLY word 0 of the filter plane of its 16 subjects (4 wave tiles): that is all level 1 looks at; the
+// other filter words (level 2, ~1 % of the survivors) and the other planes (level 3) come from L2/HBM when needed.
+// Exact like every other level: nothing is skipped unless a lower bound already exceeds the query's bound.
+// Where the prefilter stops paying for a wave (dense neighbourhoods) it falls back to the plain comparison with one
+// tile's planes in registers, exactly like scan_lazy_kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int kZoneTiles = 4;
+
+template <int PS, int PQ, int W>
+__global__ __launch_bounds__(256, 4) void scan_zone_kernel(const uint4 *__restrict__ planes,
+                                                           const uint32_t *__restrict__ qrec, ScanArgs a) {
+    constexpr int T = kZoneTiles;
+    constexpr int RS = qrec_stride(PQ, W);
+    constexpr int RV = RS / 4;
+    constexpr int NV = (kChunk * RV + 255) / 256;
+    constexpr int FP = filter_plane(PQ);
+    constexpr int BS = bound_slot(W);
+    constexpr bool kPair = SMAFA_AND_PAIR && W > 1;
+    __shared__ uint4 stage[2][kChunk * RV];
+    __shared__ RowStage rs;
+    int buf = 0;  // LDS buffer of the chunk being computed = parity of the row stage it appends to
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    if (tid == 0) rs.n[0] = rs.n[1] = 0;  // published by the barrier in front of the chunk loop
+    const uint32_t wg_tile = blockIdx.x % a.n_wg_tiles;
+    const uint32_t qblock = blockIdx.x / a.n_wg_tiles;
+    const uint32_t tile0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.tile_begin + (wg_tile * kWgWaves + wave) * T));
+    const bool active = tile0 < a.tile_end;
+    const uint32_t q0 = a.q_begin + qblock * a.qb_size;
+    const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
+
+    // word 0 of the filter plane of this lane's 16 subjects; tile slots past the range copy tile_begin (valid memory)
+    uint4 f0[T];
+    auto load_filter = [&]() {
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const bool live = tile0 + t < a.tile_end;
+            f0[t] = planes[(size_t)(live ? tile0 + t : a.tile_begin) * (PS * W * 64) + (FP * W) * 64 + lane];
+        }
+    };
+    load_filter();
+    // zone words of this wave's tiles: lane t keeps tile slot t's four words for the whole kernel (4 VGPRs; sixteen
+    // scalar registers ran out, and a load per tile and chunk sits on the critical path); v_readlane hands them out
+    uint4 vz = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < (uint32_t)T && tile0 + lane < a.tile_end) vz = a.zone[tile0 + lane];
+
+    uint4 pre[NV];
+    auto fetch = [&](uint32_t qc) {
+        const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
+        const uint4 *src = reinterpret_cast<const uint4 *>(qrec + (size_t)qc * RS);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const uint32_t idx = tid + v * 256;
+            if (idx < nqc * RV) {
+                uint4 x = src[idx];
+                if (idx % RV == BS / 4) {
+                    const uint32_t nu = ~(a.thr ? ld_relaxed(a.thr + qc + idx / RV) : a.thr0);
+                    if ((BS & 3) == 0) x.x = nu;
+                    else if ((BS & 3) == 1) x.y = nu;
+                    else if ((BS & 3) == 2) x.z = nu;
+                    else x.w = nu;
+                }
+                pre[v] = x;
+            }
+        }
+    };
+    auto commit = [&](int b, uint32_t qc) {
+        const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const uint32_t idx = tid + v * 256;
+            if (idx < nqc * RV) stage[b][idx] = pre[v];
+        }
+    };
+    auto read_record = [&](const uint4 *rec, uint32_t(&qw)[RS]) {
+#pragma unroll
+        for (int v = 0; v < RV; v++) {
+            const uint4 x = rec[v];
+            qw[4 * v + 0] = x.x;
+            qw[4 * v + 1] = x.y;
+            qw[4 * v + 2] = x.z;
+            qw[4 * v + 3] = x.w;
+        }
+    };
+    // exact comparison of one query against the 4 subjects this lane owns in `tile`, the tile's words streamed from
+    // L2/HBM one 32-column word at a time (PS vectors live, not PS * W)
+    auto stream_compare = [&](uint32_t tile, const uint32_t(&qw)[RS], uint32_t q) {
+        const uint32_t U = ~qw[BS];
+        const uint4 *src = planes + (size_t)tile * (PS * W * 64) + lane;
+        uint32_t d[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            uint32_t extra = 0;
+#pragma unroll
+            for (int p = PS; p < PQ; p++) extra |= qw[qslot(PQ, W, p, w)];
+            uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
+#pragma unroll
+            for (int p = 0; p < PS; p++) {
+                const uint4 v = src[(p * W + w) * 64];
+                const uint32_t qv = qw[qslot(PQ, W, p, w)];
+                m0 = or_xor(m0, v.x, qv);
+                m1 = or_xor(m1, v.y, qv);
+                m2 = or_xor(m2, v.z, qv);
+                m3 = or_xor(m3, v.w, qv);
+            }
+            d[0] += __builtin_popcount(m0);
+            d[1] += __builtin_popcount(m1);
+            d[2] += __builtin_popcount(m2);
+            d[3] += __builtin_popcount(m3);
+        }
+        const uint32_t subj0 = tile * kWaveTile + lane * 4u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, rs, buf, q, subj0 + k, d[k]);
+    };
+
+    if (q0 < q1) {
+        fetch(q0);
+        commit(0, q0);
+    }
+    __syncthreads();
+    bool filter_on = a.use_filter != 0;
+    uint32_t chunk_no = 0;
+    for (uint32_t qc = q0; qc < q1; qc += kChunk, buf ^= 1, chunk_no++) {
+        const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
+        const bool more = qc + kChunk < q1;
+        if (more) fetch(qc + kChunk);  // in flight while this chunk is computed
+        if (active) {
+            const bool probe = a.use_filter && (filter_on || (chunk_no & 15u) == 0);
+            if (probe) {
+                uint32_t passes = 0;  // (query, tile) pairs of this chunk that needed the exact comparison
+                // ---- zone level: lane i holds [f0 f1 ~bound ..] of query i of the chunk
+                uint4 head = make_uint4(0u, 0u, 0u, 0u);  // lanes past the chunk: ~bound = 0 never passes
+                if (lane < nqc) head = stage[buf][lane * RV];
+                const uint32_t hq0 = head.x, hq1 = W > 1 ? head.y : 0u, hnu = BS == 1 ? head.y : head.z;
+                // Tile by tile, as a RUN-TIME loop: one copy of the code below (four inlined copies of the tile
+                // fetch made the compiler hoist forty 64-bit addresses and spill them), on a copy of the tile's word.
+#pragma unroll 1
+                for (uint32_t t = 0; t < (uint32_t)T; t++) {
+                    const uint32_t tile = tile0 + t;
+                    if (tile >= a.tile_end) break;
+                    const uint32_t zc0 = (uint32_t)__builtin_amdgcn_readlane((int)vz.x, (int)t);
+                    const uint32_t zm0 = (uint32_t)__builtin_amdgcn_readlane((int)vz.y, (int)t);
+                    uint32_t u = __builtin_popcount((hq0 ^ zc0) & zm0) + hnu;
+                    if (W > 1) {
+                        const uint32_t zc1 = (uint32_t)__builtin_amdgcn_readlane((int)vz.z, (int)t);
+                        const uint32_t zm1 = (uint32_t)__builtin_amdgcn_readlane((int)vz.w, (int)t);
+                        u += __builtin_popcount((hq1 ^ zc1) & zm1);
+                    }
+                    unsigned long long m = __ballot((int32_t)u < 0);  // queries of the chunk this tile cannot exclude
+                    if (m == 0ull) continue;
+                    uint4 ft = f0[0];
+#pragma unroll
+                    for (int k = 1; k < T; k++)
+                        if (t == (uint32_t)k) ft = f0[k];
+                    while (m != 0ull) {
+                        const int i = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        // ---- level 1: word 0 of the filter plane
+                        const uint32_t q0w = (uint32_t)__builtin_amdgcn_readlane((int)hq0, i);
+                        const uint32_t nu = (uint32_t)__builtin_amdgcn_readlane((int)hnu, i);
+                        const uint32_t u0 = __builtin_popcount(ft.x ^ q0w) + nu;
+                        const uint32_t u1 = __builtin_popcount(ft.y ^ q0w) + nu;
+                        const uint32_t u2 = __builtin_popcount(ft.z ^ q0w) + nu;
+                        const uint32_t u3 = __builtin_popcount(ft.w ^ q0w) + nu;
+                        if (__ballot((int32_t)(or3(u0, u1, u2) | u3) < 0) == 0ull) continue;
+                        // ---- level 2 (rare): the filter plane folded over all its words, words 1.. from L2/HBM
+                        uint32_t qw[RS];
+                        read_record(&stage[buf][(uint32_t)i * RV], qw);
+                        uint32_t m0 = ft.x ^ qw[0], m1 = ft.y ^ qw[0], m2 = ft.z ^ qw[0], m3 = ft.w ^ qw[0];
+                        if (W > 1) {
+                            const uint4 *src = planes + (size_t)tile * (PS * W * 64) + (FP * W) * 64 + lane;
+#pragma unroll
+                            for (int w = 1; w < W; w++) {
+                                const uint4 v = src[w * 64];
+                                m0 = or_xor(m0, v.x, qw[qslot(PQ, W, FP, w)]);
+                                m1 = or_xor(m1, v.y, qw[qslot(PQ, W, FP, w)]);
+                                m2 = or_xor(m2, v.z, qw[qslot(PQ, W, FP, w)]);
+                                m3 = or_xor(m3, v.w, qw[qslot(PQ, W, FP, w)]);
+                            }
+                            if (kPair) {  // two subjects per popcount first (see scan_kernel)
+                                const uint32_t sign = (__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu);
+                                if (__ballot((int32_t)sign < 0) == 0ull) continue;
+                            }
+                            const uint32_t each = or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
+                                                      __builtin_popcount(m2) + nu) |
+                                                  (__builtin_popcount(m3) + nu);
+                            if (__ballot((int32_t)each < 0) == 0ull) continue;
+                        }
+                        // ---- level 3: all planes, exactly
+                        passes++;
+                        stream_compare(tile, qw, qc + (uint32_t)i);
+                    }
+                }
+                filter_on = passes * 4u <= nqc;
+            } else {
+                // dense neighbourhoods: one pass over the chunk per tile, that tile's planes in registers
+                for (uint32_t t = 0; t < (uint32_t)T; t++) {
+                    const uint32_t tile = tile0 + t;
+                    if (tile >= a.tile_end) break;
+                    uint4 s[PS * W];
+                    const uint4 *src = planes + (size_t)tile * (PS * W * 64) + lane;
+#pragma unroll
+                    for (int i = 0; i < PS * W; i++) s[i] = src[i * 64];
+                    const uint4 *rec = &stage[buf][0];
+                    for (uint32_t i = 0; i < nqc; i++, rec += RV) {
+                        uint32_t qw[RS];
+                        read_record(rec, qw);
+                        const uint32_t U = ~qw[BS];
+                        uint32_t d[4];
+#pragma unroll
+                        for (int w = 0; w < W; w++) {
+                            uint32_t extra = 0;
+#pragma unroll
+                            for (int p = PS; p < PQ; p++) extra |= qw[qslot(PQ, W, p, w)];
+                            uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
+#pragma unroll
+                            for (int p = 0; p < PS; p++) {
+                                const uint4 v = s[p * W + w];
+                                const uint32_t qv = qw[qslot(PQ, W, p, w)];
+                                m0 = or_xor(m0, v.x, qv);
+                                m1 = or_xor(m1, v.y, qv);
+                                m2 = or_xor(m2, v.z, qv);
+                                m3 = or_xor(m3, v.w, qv);
+                            }
+                            d[0] = (w ? d[0] : 0u) + __builtin_popcount(m0);
+                            d[1] = (w ? d[1] : 0u) + __builtin_popcount(m1);
+                            d[2] = (w ? d[2] : 0u) + __builtin_popcount(m2);
+                            d[3] = (w ? d[3] : 0u) + __builtin_popcount(m3);
+                        }
+                        const uint32_t subj0 = tile * kWaveTile + lane * 4u;
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, rs, buf, qc + i, subj0 + k, d[k]);
+                    }
+                }
+                load_filter();  // not kept across the walk (its registers hold the tile meanwhile): fetched again
+            }
+        }
+        if (more) commit(buf ^ 1, qc + kChunk);
+        __syncthreads();
+        if (a.hits) flush_rows(a, rs, buf);
+    }
+    finish_rows(a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Up to 64 queries against a sorted store (north_star's "each query is broadcast against all subjects", one query or
+// a handful per pass).  Nothing is staged: lane i loads the head of query i straight from the record array, the wave
+// checks its T tiles' zone words against all (up to) 64 queries at once, and only the tiles that some query survives
+// are fetched at all — one pass reads the zone array (16 B per 256 subjects) plus the filter words of the surviving
+// tiles, instead of streaming the whole filter plane.  Levels 1-3 as in scan_lazy_kernel; the rare levels read the
+// query record from global memory.
+// ---------------------------------------------------------------------------------------------
+template <int PS, int PQ, int W>
+__global__ __launch_bounds__(256) void scan_zone_few_kernel(const uint4 *__restrict__ planes,
+                                                            const uint32_t *__restrict__ qrec, ScanArgs a) {
+    constexpr int T = kZoneTiles;
+    constexpr int RS = qrec_stride(PQ, W);
+    constexpr int RV = RS / 4;
+    constexpr int FP = filter_plane(PQ);
+    constexpr int BS = bound_slot(W);
+    constexpr bool kPair = SMAFA_AND_PAIR && W > 1;
+    __shared__ RowStage rs;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    if (tid == 0) rs.n[0] = rs.n[1] = 0;
+    __syncthreads();
+    const uint32_t tile0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.tile_begin + (blockIdx.x * kWgWaves + wave) * T));
+    const uint32_t nq = a.q_end - a.q_begin;  // <= 64: the host picks this kernel
+    if (tile0 < a.tile_end) {
+        uint4 vz = make_uint4(0u, 0u, 0u, 0u);  // lane t: zone words of tile slot t
+        if (lane < (uint32_t)T && tile0 + lane < a.tile_end) vz = a.zone[tile0 + lane];
+        uint4 head = make_uint4(0u, 0u, 0u, 0u);  // lane i: [f0 f1 bound ..] of query i; lanes past nq never pass
+        uint32_t hnu = 0;
+        if (lane < nq) {
+            head = reinterpret_cast<const uint4 *>(qrec + (size_t)(a.q_begin + lane) * RS)[0];
+            hnu = ~(a.thr ? ld_relaxed(a.thr + a.q_begin + lane) : a.thr0);
+        }
+        const uint32_t hq0 = head.x, hq1 = W > 1 ? head.y : 0u;
+        unsigned long long pass[T];
+        uint4 f0[T];  // word 0 of the filter plane of the tiles some query survives
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const uint32_t zc0 = (uint32_t)__builtin_amdgcn_readlane((int)vz.x, t);
+            const uint32_t zm0 = (uint32_t)__builtin_amdgcn_readlane((int)vz.y, t);
+            uint32_t u = __builtin_popcount((hq0 ^ zc0) & zm0) + hnu;
+            if (W > 1) {
+                const uint32_t zc1 = (uint32_t)__builtin_amdgcn_readlane((int)vz.z, t);
+                const uint32_t zm1 = (uint32_t)__builtin_amdgcn_readlane((int)vz.w, t);
+                u += __builtin_popcount((hq1 ^ zc1) & zm1);
+            }
+            pass[t] = tile0 + t < a.tile_end ? __ballot((int32_t)u < 0) : 0ull;
+            if (pass[t] != 0ull) {  // all surviving tiles' loads are in flight before the first is used
+                f0[t] = planes[(size_t)(tile0 + t) * (PS * W * 64) + (FP * W) * 64 + lane];
+            }
+        }
+#pragma unroll 1
+        for (uint32_t t = 0; t < (uint32_t)T; t++) {
+            unsigned long long m = 0ull;
+            uint4 ft = f0[0];
+#pragma unroll
+            for (int k = 0; k < T; k++)
+                if (t == (uint32_t)k) {
+                    m = pass[k];
+                    ft = f0[k];
+                }
+            const uint32_t tile = tile0 + t;
+            while (m != 0ull) {
+                const int i = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const uint32_t q0w = (uint32_t)__builtin_amdgcn_readlane((int)hq0, i);
+                const uint32_t nu = (uint32_t)__builtin_amdgcn_readlane((int)hnu, i);
+                const uint32_t u0 = __builtin_popcount(ft.x ^ q0w) + nu;
+                const uint32_t u1 = __builtin_popcount(ft.y ^ q0w) + nu;
+                const uint32_t u2 = __builtin_popcount(ft.z ^ q0w) + nu;
+                const uint32_t u3 = __builtin_popcount(ft.w ^ q0w) + nu;
+                if (__ballot((int32_t)(or3(u0, u1, u2) | u3) < 0) == 0ull) continue;
+                // levels 2 and 3 (rare): the whole record, from global memory
+                const uint32_t q = a.q_begin + (uint32_t)i;
+                uint32_t qw[RS];
+                const uint4 *rec = reinterpret_cast<const uint4 *>(qrec + (size_t)q * RS);
+#pragma unroll
+                for (int v = 0; v < RV; v++) {
+                    const uint4 x = rec[v];
+                    qw[4 * v + 0] = x.x;
+                    qw[4 * v + 1] = x.y;
+                    qw[4 * v + 2] = x.z;
+                    qw[4 * v + 3] = x.w;
+                }
+                qw[BS] = nu;  // the record's bound slot is filled in at staging time elsewhere; here from thr / thr0
+                uint32_t m0 = ft.x ^ qw[0], m1 = ft.y ^ qw[0], m2 = ft.z ^ qw[0], m3 = ft.w ^ qw[0];
+#pragma unroll
+                for (int w = 1; w < W; w++) {  // filter words 1.. of the tile, from L2/HBM
+                    const uint4 v = planes[(size_t)tile * (PS * W * 64) + (FP * W + w) * 64 + lane];
+                    m0 = or_xor(m0, v.x, qw[qslot(PQ, W, FP, w)]);
+                    m1 = or_xor(m1, v.y, qw[qslot(PQ, W, FP, w)]);
+                    m2 = or_xor(m2, v.z, qw[qslot(PQ, W, FP, w)]);
+                    m3 = or_xor(m3, v.w, qw[qslot(PQ, W, FP, w)]);
+                }
+                if (kPair) {
+                    const uint32_t sign = (__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu);
+                    if (__ballot((int32_t)sign < 0) == 0ull) continue;
+                }
+                if (W > 1) {
+                    const uint32_t each = or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
+                                              __builtin_popcount(m2) + nu) |
+                                          (__builtin_popcount(m3) + nu);
+                    if (__ballot((int32_t)each < 0) == 0ull) continue;
+                }
+                // exact comparison against the 4 subjects this lane owns in the tile
+                const uint4 *src = planes + (size_t)tile * (PS * W * 64) + lane;
+                const uint32_t U = ~nu;
+                uint32_t d[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int w = 0; w < W; w++) {
+                    uint32_t extra = 0;
+#pragma unroll
+                    for (int p = PS; p < PQ; p++) extra |= qw[qslot(PQ, W, p, w)];
+                    uint32_t x0 = extra, x1 = extra, x2 = extra, x3 = extra;
+#pragma unroll
+                    for (int p = 0; p < PS; p++) {
+                        const uint4 v = src[(p * W + w) * 64];
+                        const uint32_t qv = qw[qslot(PQ, W, p, w)];
+                        x0 = or_xor(x0, v.x, qv);
+                        x1 = or_xor(x1, v.y, qv);
+                        x2 = or_xor(x2, v.z, qv);
+                        x3 = or_xor(x3, v.w, qv);
+                    }
+                    d[0] += __builtin_popcount(x0);
+                    d[1] += __builtin_popcount(x1);
+                    d[2] += __builtin_popcount(x2);
+                    d[3] += __builtin_popcount(x3);
+                }
+                const uint32_t subj0 = tile * kWaveTile + lane * 4u;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, rs, 0, q, subj0 + k, d[k]);
+            }
+        }
+    }
+    __syncthreads();
+    if (a.hits) flush_rows(a, rs, 0);
+    finish_rows(a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -699,6 +1175,9 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
     const uint32_t chunk = min((uint32_t)kChunk, (uint32_t)kWideStage / RV);  // >= 1: the host checks wide_fits()
     __shared__ uint4 stage[2][kWideStage];
     __shared__ uint4 heads[2][kChunk][HV];  // leading vector(s) of every staged record, at a compile-time stride
+    __shared__ RowStage rs;
+    int buf = 0;  // LDS buffer of the chunk being computed = parity of the row stage it appends to
+    if (threadIdx.x == 0) rs.n[0] = rs.n[1] = 0;  // published by the barrier in front of the chunk loop
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -776,7 +1255,7 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, q, subj0 + k, d[k]);
+                if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, rs, buf, q, subj0 + k, d[k]);
         }
     };
     // level 3: full comparison of the query record at `rec` (LDS) against the 4 subjects this lane owns in `tile`
@@ -909,7 +1388,6 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
         commit(0, q0);
     }
     __syncthreads();
-    int buf = 0;
     bool filter_on = a.use_filter != 0;
     bool level1_on = true;
     uint32_t chunk_no = 0;
@@ -1011,7 +1489,9 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
         }
         if (more) commit(buf ^ 1, qc + chunk);
         __syncthreads();
+        if (!SEED && a.hits) flush_rows(a, rs, buf);
     }
+    if (!SEED) finish_rows(a);
 }
 
 // Any (planes, words) shape — the fallback for L > 128 when the bound is too loose for scan_wide_kernel's
@@ -1024,12 +1504,15 @@ constexpr int kGenericTiles = 4;
 __global__ __launch_bounds__(256) void scan_generic_kernel(const uint4 *__restrict__ planes,
                                                            const uint32_t *__restrict__ qrec, ScanArgs a, uint32_t PS,
                                                            uint32_t PQ, uint32_t W, uint32_t QS) {
+    __shared__ RowStage rs;
+    if (threadIdx.x == 0) rs.n[0] = rs.n[1] = 0;
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t wg_tile = blockIdx.x % a.n_wg_tiles;
     const uint32_t qblock = blockIdx.x / a.n_wg_tiles;
     const uint32_t tile0 = a.tile_begin + (wg_tile * kWgWaves + wave) * kGenericTiles;
-    if (tile0 >= a.tile_end) return;  // no barrier in this kernel
+    const bool active = tile0 < a.tile_end;  // idle waves still take part in the barriers of the row flushes
     const uint32_t FP = (uint32_t)filter_plane((int)PQ);
     const size_t tile_stride = (size_t)PS * W * 64;
     uint4 f[kGenericTiles];
@@ -1039,57 +1522,65 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(const uint4 *__restri
                                       : make_uint4(0, 0, 0, 0);
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
     const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
-    for (uint32_t q = q0; q < q1; q++) {
-        const uint32_t U = a.thr ? ld_relaxed(a.thr + q) : a.thr0;
-        const uint32_t *qr = qrec + (size_t)q * QS;
-        bool go = true;
-        if (a.use_filter) {
-            const uint32_t q0w = qr[0], nu = ~U;  // slot 0 = word 0 of the prefilter plane
-            uint32_t any = 0;
+    int parity = 0;
+    for (uint32_t qc = q0; qc < q1; qc += kChunk, parity ^= 1) {
+        const uint32_t qe = min(qc + (uint32_t)kChunk, q1);
+        for (uint32_t q = qc; active && q < qe; q++) {
+            const uint32_t U = a.thr ? ld_relaxed(a.thr + q) : a.thr0;
+            const uint32_t *qr = qrec + (size_t)q * QS;
+            bool go = true;
+            if (a.use_filter) {
+                const uint32_t q0w = qr[0], nu = ~U;  // slot 0 = word 0 of the prefilter plane
+                uint32_t any = 0;
 #pragma unroll
-            for (int t = 0; t < kGenericTiles; t++)
-                any |= or3(__builtin_popcount(f[t].x ^ q0w) + nu, __builtin_popcount(f[t].y ^ q0w) + nu,
-                           __builtin_popcount(f[t].z ^ q0w) + nu) |
-                       (__builtin_popcount(f[t].w ^ q0w) + nu);
-            go = __ballot((int32_t)any < 0) != 0ull;  // wave-uniform
-        }
-        if (!go) continue;
-        for (uint32_t t = 0; t < (uint32_t)kGenericTiles; t++) {
-            const uint32_t tile = tile0 + t;
-            if (tile >= a.tile_end) break;
-            const uint4 *src = planes + (size_t)tile * tile_stride + lane;
-            const uint32_t subj0 = tile * kWaveTile + lane * 4u;
-            uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-            for (uint32_t w = 0; w < W; w++) {
-                uint32_t extra = 0;
-                for (uint32_t p = PS; p < PQ; p++) extra |= qr[qslot((int)PQ, (int)W, (int)p, (int)w)];
-                uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
-                for (uint32_t p = 0; p < PS; p++) {
-                    const uint4 v = src[(p * W + w) * 64];
-                    const uint32_t qv = qr[qslot((int)PQ, (int)W, (int)p, (int)w)];
-                    m0 = or_xor(m0, v.x, qv);
-                    m1 = or_xor(m1, v.y, qv);
-                    m2 = or_xor(m2, v.z, qv);
-                    m3 = or_xor(m3, v.w, qv);
-                }
-                d0 += __builtin_popcount(m0);
-                d1 += __builtin_popcount(m1);
-                d2 += __builtin_popcount(m2);
-                d3 += __builtin_popcount(m3);
+                for (int t = 0; t < kGenericTiles; t++)
+                    any |= or3(__builtin_popcount(f[t].x ^ q0w) + nu, __builtin_popcount(f[t].y ^ q0w) + nu,
+                               __builtin_popcount(f[t].z ^ q0w) + nu) |
+                           (__builtin_popcount(f[t].w ^ q0w) + nu);
+                go = __ballot((int32_t)any < 0) != 0ull;  // wave-uniform
             }
-            if (d0 <= U && subj0 + 0 < a.n_subjects) emit(a, q, subj0 + 0, d0);
-            if (d1 <= U && subj0 + 1 < a.n_subjects) emit(a, q, subj0 + 1, d1);
-            if (d2 <= U && subj0 + 2 < a.n_subjects) emit(a, q, subj0 + 2, d2);
-            if (d3 <= U && subj0 + 3 < a.n_subjects) emit(a, q, subj0 + 3, d3);
+            if (!go) continue;
+            for (uint32_t t = 0; t < (uint32_t)kGenericTiles; t++) {
+                const uint32_t tile = tile0 + t;
+                if (tile >= a.tile_end) break;
+                const uint4 *src = planes + (size_t)tile * tile_stride + lane;
+                const uint32_t subj0 = tile * kWaveTile + lane * 4u;
+                uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+                for (uint32_t w = 0; w < W; w++) {
+                    uint32_t extra = 0;
+                    for (uint32_t p = PS; p < PQ; p++) extra |= qr[qslot((int)PQ, (int)W, (int)p, (int)w)];
+                    uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
+                    for (uint32_t p = 0; p < PS; p++) {
+                        const uint4 v = src[(p * W + w) * 64];
+                        const uint32_t qv = qr[qslot((int)PQ, (int)W, (int)p, (int)w)];
+                        m0 = or_xor(m0, v.x, qv);
+                        m1 = or_xor(m1, v.y, qv);
+                        m2 = or_xor(m2, v.z, qv);
+                        m3 = or_xor(m3, v.w, qv);
+                    }
+                    d0 += __builtin_popcount(m0);
+                    d1 += __builtin_popcount(m1);
+                    d2 += __builtin_popcount(m2);
+                    d3 += __builtin_popcount(m3);
+                }
+                if (d0 <= U && subj0 + 0 < a.n_subjects) emit(a, rs, parity, q, subj0 + 0, d0);
+                if (d1 <= U && subj0 + 1 < a.n_subjects) emit(a, rs, parity, q, subj0 + 1, d1);
+                if (d2 <= U && subj0 + 2 < a.n_subjects) emit(a, rs, parity, q, subj0 + 2, d2);
+                if (d3 <= U && subj0 + 3 < a.n_subjects) emit(a, rs, parity, q, subj0 + 3, d3);
+            }
         }
+        __syncthreads();
+        if (a.hits) flush_rows(a, rs, parity);
     }
+    finish_rows(a);
 }
 
-// The literal get_distances seam (src/lib.rs:71-89): every subject's distance to ONE query.
-// out has n_wave_tiles * 256 entries (padded), one coalesced 16-byte store per lane.
+// The literal get_distances seam (src/lib.rs:71-89): every subject's distance to ONE query, written at the subject's
+// index (out has n_subjects entries; the store keeps its subjects in sorted positions, `order` maps back).
 __global__ __launch_bounds__(256) void distances_kernel(const uint4 *__restrict__ planes, uint32_t n_wave_tiles,
-                                                        uint32_t PS, uint32_t PQ, uint32_t W,
-                                                        const uint32_t *__restrict__ qrec, uint4 *__restrict__ out) {
+                                                        uint32_t n_subjects, uint32_t PS, uint32_t PQ, uint32_t W,
+                                                        const uint32_t *__restrict__ qrec,
+                                                        const uint32_t *__restrict__ order, uint32_t *__restrict__ out) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tile = blockIdx.x * kWgWaves + (threadIdx.x >> 6);
     if (tile >= n_wave_tiles) return;
@@ -1112,38 +1603,55 @@ __global__ __launch_bounds__(256) void distances_kernel(const uint4 *__restrict_
         d.z += __builtin_popcount(m.z);
         d.w += __builtin_popcount(m.w);
     }
-    out[(size_t)tile * 64 + lane] = d;
+    const uint32_t pos = tile * kWaveTile + lane * 4u;
+    if (pos + 0 < n_subjects) out[order[pos + 0]] = d.x;
+    if (pos + 1 < n_subjects) out[order[pos + 1]] = d.y;
+    if (pos + 2 < n_subjects) out[order[pos + 2]] = d.z;
+    if (pos + 3 < n_subjects) out[order[pos + 3]] = d.w;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Packing: code bytes -> bit-planes by wave64 ballot.
-// Lane c of a wave reads column 64h + c of one row; __ballot(bit p of the code) IS the 64-column
-// slice of plane p (low half = word 2h, high half = word 2h+1).  A wave packs 64 consecutive rows,
-// parks row i's words in lane i, then stores each (plane, word) as one coalesced 256-byte row.
+// Lane c of a wave handles packed column 64h + c of one row: it reads the SOURCE column perm[64h + c] of that row and
+// re-codes the byte through tab[source column][code] (the store's layout: best columns first, best-balanced bit in
+// plane 0 — choose_layout() in engine.hip; distances are invariant under both).  __ballot(bit p of the code) IS the
+// 64-column slice of plane p (low half = word 2h, high half = word 2h+1).  A wave packs 64 consecutive rows, parks
+// row i's words in lane i, then stores each (plane, word) as one coalesced 256-byte row.
 //   mode 0: subject tile layout   out[((tile*P + p)*W + w)*256 + (row & 255)]
 //   mode 1: query record layout   out[row*QS + qslot(p, w)]
-// `first` = absolute index of codes row 0 (appends start mid-tile); rows are absolute indices.
+// `first` = position of the first packed row (appends start mid-tile).  The row packed at position first + i is row
+// src[i] of `codes` (src == NULL: row i) — the sorted order of an append — and order[first + i] = first + src[i] is the
+// subject index a scan reports for it.
 // ---------------------------------------------------------------------------------------------
 template <int P>
-__global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *codes, uint64_t first, uint64_t n, uint32_t L,
-                                                        uint32_t W, uint32_t *out, int mode, uint32_t QS) {
+__global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *codes, const uint32_t *src, uint64_t first,
+                                                        uint64_t n, uint32_t L, uint32_t W, uint32_t *out, int mode,
+                                                        uint32_t QS, const uint16_t *__restrict__ perm,
+                                                        const uint8_t *__restrict__ tab, uint32_t *order) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t group = (uint64_t)blockIdx.x * kWgWaves + (threadIdx.x >> 6);
-    const uint64_t base = (first / 64 + group) * 64;  // absolute row of lane 0's slot
+    const uint64_t base = (first / 64 + group) * 64;  // position of lane 0's slot
     const uint64_t end = first + n;
     if (base >= end) return;
     const uint64_t my_row = base + lane;
     const bool mine_valid = my_row >= first && my_row < end;
+    // source row of the position this lane parks (and, via readlane, of every position the wave packs)
+    uint32_t my_src = 0;
+    if (mine_valid) my_src = src ? src[my_row - first] : (uint32_t)(my_row - first);
+    if (mine_valid && order) order[my_row] = (uint32_t)first + my_src;
     for (uint32_t h = 0; h * 2 < W; h++) {
         const uint32_t col = 64 * h + lane;
+        const uint32_t scol = col < L ? perm[col] : 0u;
+        const uint8_t *tcol = tab + (size_t)scol * 32;
         uint32_t lo[P], hi[P];
 #pragma unroll
         for (int p = 0; p < P; p++) lo[p] = hi[p] = 0;
 #pragma unroll 8
         for (uint32_t i = 0; i < 64; i++) {
             const uint64_t row = base + i;  // wave-uniform
+            const uint32_t srow = (uint32_t)__builtin_amdgcn_readlane((int)my_src, (int)i);
             uint32_t code = 0;
-            if (row >= first && row < end && col < L) code = codes[(row - first) * L + col];
+            if (row >= first && row < end && col < L) code = tcol[codes[(size_t)srow * L + scol] & 31u];
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 const unsigned long long b = __ballot((code >> p) & 1u);
@@ -1173,6 +1681,81 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *codes, ui
     }
 }
 
+// Sort key of a subject row: its filter-plane words 0 and 1 (after the layout's column order and re-coding), each
+// bit-reversed (column 0 = most significant: the layout puts the most informative columns first) and run through the
+// inverse Gray code, so that rows whose keys are close in the sorted order differ in few LEADING filter bits even
+// across a power-of-two boundary (a plain binary order loses every bit above the boundary a tile straddles).
+__device__ __forceinline__ uint32_t gray_rank(uint32_t x) {
+    x = __brev(x);
+    x ^= x >> 1;
+    x ^= x >> 2;
+    x ^= x >> 4;
+    x ^= x >> 8;
+    x ^= x >> 16;
+    return x;
+}
+
+__global__ void row_keys_kernel(const uint8_t *__restrict__ codes, uint64_t n, uint32_t L, const uint16_t *__restrict__ perm,
+                                const uint8_t *__restrict__ tab, unsigned long long *__restrict__ keys,
+                                uint32_t *__restrict__ iota) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *row = codes + (size_t)i * L;
+    uint32_t w0 = 0, w1 = 0;
+    const uint32_t c0 = min(L, 32u), c1 = min(L, 64u);
+    for (uint32_t j = 0; j < c0; j++) {
+        const uint32_t sc = perm[j];
+        w0 |= (uint32_t)(tab[sc * 32 + (row[sc] & 31u)] & 1u) << j;
+    }
+    for (uint32_t j = 32; j < c1; j++) {
+        const uint32_t sc = perm[j];
+        w1 |= (uint32_t)(tab[sc * 32 + (row[sc] & 31u)] & 1u) << (j - 32);
+    }
+    keys[i] = ((unsigned long long)gray_rank(w0) << 32) | gray_rank(w1);
+    iota[i] = (uint32_t)i;
+}
+
+// zone[tile] = {c0, m0, c1, m1}: m_w = the bits of filter word w on which all subjects of the wave tile agree, c_w =
+// their common value there.  For a query word q, popcount((q ^ c_w) & m_w) mismatching columns are shared by every
+// subject of the tile.  One wave per tile; positions past n_subjects (the padding of the last tile) do not count.
+__global__ __launch_bounds__(256) void zone_kernel(const uint4 *__restrict__ planes, uint32_t PS, uint32_t W,
+                                                   uint32_t tile_begin, uint32_t tile_end, uint32_t n_subjects,
+                                                   uint4 *__restrict__ zone) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = tile_begin + blockIdx.x * kWgWaves + (threadIdx.x >> 6);
+    if (tile >= tile_end) return;
+    const uint4 *t = planes + (size_t)tile * ((size_t)PS * W * 64) + lane;  // plane 0 is the filter plane
+    const uint32_t pos = tile * kWaveTile + lane * 4u;
+    uint32_t land[2] = {0xffffffffu, 0xffffffffu}, lor[2] = {0u, 0u};
+    for (uint32_t w = 0; w < 2 && w < W; w++) {
+        const uint4 v = t[w * 64];
+        const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (pos + k < n_subjects) {
+                land[w] &= x[k];
+                lor[w] |= x[k];
+            }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+            land[w] &= (uint32_t)__shfl_xor((int)land[w], off, 64);
+            lor[w] |= (uint32_t)__shfl_xor((int)lor[w], off, 64);
+        }
+    }
+    if (lane == 0) {
+        uint4 z;
+        z.y = ~(land[0] ^ lor[0]);
+        z.x = land[0] & z.y;
+        z.w = W > 1 ? ~(land[1] ^ lor[1]) : 0u;
+        z.z = W > 1 ? (land[1] & z.w) : 0u;
+        if (lor[0] == 0u && land[0] == 0xffffffffu) z = make_uint4(0u, 0u, 0u, 0u);  // an empty tile shares nothing
+        zone[tile] = z;
+    }
+}
+
 // Re-layout the subject block from p_old to p_new planes per subject (new planes zero): the N-free
 // nucleotide store gains its third plane the first time a subject with an N is appended.
 __global__ void replane_kernel(const uint32_t *src, uint32_t *dst, uint64_t n_tiles, uint32_t p_old, uint32_t p_new,
@@ -1185,54 +1768,37 @@ __global__ void replane_kernel(const uint32_t *src, uint32_t *dst, uint64_t n_ti
     dst[i] = p < p_old ? src[tile * (uint64_t)p_old * W * 256 + (uint64_t)p * W * 256 + rest] : 0u;
 }
 
-// After a scan: gather the kShards row segments into one contiguous list of at most `cap` rows and publish one
-// count.  If any segment overflowed its shard_cap (rows were dropped) the published count is forced above `cap`,
-// which is the "did not fit, retry" signal of the scan API.  One workgroup per segment.
-// thr != NULL (tightening modes): the scan appended every pair that was within the bound of its query AT THAT
-// TIME; only rows within the FINAL bound can be printed, so the gather keeps `dist <= thr[query]` and drops the
-// rest — typically 50-100 appended rows per query shrink to one or two before anything is sorted or crosses PCIe.
-// Kept rows land in arbitrary order through one wave-aggregated atomic per wave (*out_count zeroed by the host).
-__global__ __launch_bounds__(256) void compact_rows_kernel(const smafa_hit *shards, const unsigned long long *counts,
-                                                           unsigned long long shard_cap, smafa_hit *out,
-                                                           unsigned long long cap, unsigned long long *out_count,
-                                                           const uint32_t *thr) {
-    const uint32_t s = blockIdx.x;
-    unsigned long long before = 0, total = 0;
-    bool dropped = false;
-    for (uint32_t i = 0; i < kShards; i++) {
-        const unsigned long long c = counts[(size_t)i * kCountStride];
-        if (c > shard_cap) dropped = true;
-        if (i < s) before += c < shard_cap ? c : shard_cap;
-        total += c;
-    }
-    const unsigned long long cs = counts[(size_t)s * kCountStride];
-    const unsigned long long mine = cs < shard_cap ? cs : shard_cap;
-    const smafa_hit *src = shards + (size_t)s * shard_cap;
-    if (thr == nullptr) {
-        for (unsigned long long i = threadIdx.x; i < mine; i += blockDim.x)
-            if (before + i < cap) out[before + i] = src[i];
-        if (s == 0 && threadIdx.x == 0) *out_count = (dropped && total <= cap) ? cap + 1 : total;
-        return;
-    }
-    if (dropped) {  // every workgroup sees the same counters: nobody appends, one thread reports
-        if (s == 0 && threadIdx.x == 0) *out_count = cap + 1;
+// After the launches of a tightening scan (max_num_hits = k): the scan appended every pair that was within the bound
+// of its query AT THAT TIME to the scratch list; only rows within the FINAL bound can be printed, so this pass keeps
+// `dist <= thr[query]` and drops the rest — typically 50-100 appended rows per query shrink to one or two before
+// anything is sorted or crosses PCIe.  Kept rows land in `out` in arbitrary order through one wave-aggregated atomic
+// per wave (*out_count zeroed by the host); *out_count keeps counting past cap.  If the scratch list itself
+// overflowed (rows were dropped: the answer is incomplete) nothing is appended and *out_count = cap + 1, the
+// "did not fit" signal of the scan API.
+__global__ __launch_bounds__(256) void filter_rows_kernel(const smafa_hit *list, const unsigned long long *list_count,
+                                                          unsigned long long list_cap, smafa_hit *out,
+                                                          unsigned long long cap, unsigned long long *out_count,
+                                                          const uint32_t *thr) {
+    const unsigned long long total = *list_count;
+    if (total > list_cap) {  // every workgroup sees the same counter: nobody appends, one thread reports
+        if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = cap + 1;
         return;
     }
     const uint32_t lane = threadIdx.x & 63u;
-    for (unsigned long long base = 0; base < mine; base += blockDim.x) {  // uniform trip count per workgroup
-        const unsigned long long i = base + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < total; base += stride) {
+        const unsigned long long i = base + threadIdx.x;  // uniform trip count per workgroup
         smafa_hit h = {0, 0, 0};
         bool keep = false;
-        if (i < mine) {
-            h = src[i];
+        if (i < total) {
+            h = list[i];
             keep = h.dist <= thr[h.query];
         }
         const unsigned long long mask = __ballot(keep);
         if (mask == 0ull) continue;
         unsigned long long first = 0;
         if (lane == 0) first = atomicAdd(out_count, (unsigned long long)__builtin_popcountll(mask));
-        first = ((unsigned long long)(uint32_t)__shfl((int)(first >> 32), 0, 64) << 32) |
-                (uint32_t)__shfl((int)(first & 0xffffffffull), 0, 64);
+        first = shfl_u64(first, 0);
         const unsigned long long slot = first + lanes_below(mask);
         if (keep && slot < cap) out[slot] = h;
     }

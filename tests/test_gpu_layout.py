@@ -1,0 +1,190 @@
+"""GPU parity of the round-2 store layout: per-column re-coding and column order chosen from the data, subjects kept
+sorted by their filter words (positions != subject indices), the zone level of the filter-plane-resident kernel, and
+the single-launch row append (LDS-staged rows, one counter, exact totals).  Everything against the oracle, bit-exact,
+through the C ABI."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+import smafa_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    smafa_amd.build()
+    assert smafa_amd.device_count() >= 1
+
+
+def skewed_store(rng, n, L, n_letters, conserved_frac=0.5, families=0):
+    """columns with very different letter distributions: a share of them nearly constant (one dominant letter per
+    column), the rest uniform — what the layout's column order and re-coding react to; optionally family structure"""
+    s = rng.integers(0, n_letters, size=(n, L), dtype=np.uint8)
+    cons = rng.random(L) < conserved_frac
+    dom = rng.integers(0, n_letters, size=L, dtype=np.uint8)
+    keep = rng.random((n, L)) < 0.93
+    s[:, cons] = np.where(keep[:, cons], dom[cons][None, :], s[:, cons])
+    if families:
+        roots = s[rng.integers(0, n, size=families)]
+        member = rng.integers(0, families, size=n)
+        mut = rng.random((n, L)) < 0.15
+        s = np.where(mut, s, roots[member])
+    return np.ascontiguousarray(s)
+
+
+def queries_from(rng, s, q, n_letters, max_subs):
+    out = s[rng.integers(0, len(s), size=q)].copy()
+    for r in out:
+        for _ in range(rng.integers(0, max_subs + 1)):
+            r[rng.integers(0, s.shape[1])] = rng.integers(0, n_letters)
+    return out
+
+
+def expected_with_k(all_hits, k):
+    out, i = [], 0
+    while i < len(all_hits):
+        j = i
+        while j < len(all_hits) and all_hits[j]["query"] == all_hits[i]["query"]:
+            j += 1
+        grp = all_hits[i:j]
+        kth = grp[k - 1]["dist"] if len(grp) >= k else 0xFFFFFFFF
+        out.append(grp[grp["dist"] <= kth])
+        i = j
+    return np.concatenate(out) if out else all_hits[:0]
+
+
+@pytest.fixture
+def zone_env():
+    """SMAFA_ZONE / SMAFA_SORT are read when a handle is created"""
+    old = {k: os.environ.get(k) for k in ("SMAFA_ZONE", "SMAFA_SORT")}
+    yield os.environ
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.parametrize("alphabet,n_letters", [(0, 4), (0, 5), (1, 20), (1, 28)])
+@pytest.mark.parametrize("L", [20, 60, 100, 150])
+@pytest.mark.parametrize("zone", ["0", "1", "2"])
+def test_skewed_columns_sorted_store_all_modes(zone_env, alphabet, n_letters, L, zone):
+    """stores big enough to be sorted (>= 4096 rows per append), skewed columns, families: rows must not depend on the
+    layout, on the order of positions, or on the zone level (off / automatic / forced)"""
+    zone_env["SMAFA_ZONE"] = zone
+    rng = np.random.default_rng(L * 31 + n_letters + 7 * int(zone))
+    n = 9000
+    s = skewed_store(rng, n, L, n_letters, families=40 if L >= 60 else 0)
+    q = queries_from(rng, s, 150, n_letters, 7)
+    store = smafa_amd.SubjectStore(L, alphabet)
+    store.push(s)
+    for D in (0, 2, 5, min(9, L), L):
+        got = store.scan(q, max_divergence=D)
+        assert got.tobytes() == oracle.scan_codes(s, q, D).tobytes(), (alphabet, L, D, zone)
+    for D, k in ((5, 1), (None, 1), (4, 3), (None, 6)):
+        got = store.scan(q, max_divergence=D, max_num_hits=k)
+        want = expected_with_k(oracle.scan_codes(s, q, L if D is None else D), k)
+        assert got.tobytes() == want.tobytes(), (alphabet, L, D, k, zone)
+    d = store.get_distances(q[0])
+    assert (d == oracle.distances_codes(s, q[0])).all()
+    store.close()
+
+
+def test_zone_kernel_is_the_one_that_runs_when_forced(zone_env):
+    zone_env["SMAFA_ZONE"] = "2"
+    rng = np.random.default_rng(5)
+    s = rng.integers(0, 20, size=(20000, 60), dtype=np.uint8)
+    q = queries_from(rng, s, 300, 20, 8)
+    store = smafa_amd.SubjectStore(60, 1)
+    store.push(s)
+    got = store.scan(q, max_divergence=5)
+    assert got.tobytes() == oracle.scan_codes(s, q, 5).tobytes()
+    assert store.last_scan_kernel() == "smafa::scan_zone_kernel<5, 5, 2>"
+    for few in (1, 3, 64):  # a handful of queries per pass: tiles fetched on demand
+        one = store.scan(q[:few], max_divergence=5)
+        assert one.tobytes() == oracle.scan_codes(s, q[:few], 5).tobytes()
+        assert store.last_scan_kernel() == "smafa::scan_zone_few_kernel<5, 5, 2>"
+    store.close()
+    zone_env["SMAFA_ZONE"] = "0"
+    store = smafa_amd.SubjectStore(60, 1)
+    store.push(s)
+    assert store.scan(q, max_divergence=5).tobytes() == got.tobytes()
+    assert store.last_scan_kernel() == "smafa::scan_lazy_kernel<5, 5, 2, 4, false>"
+    store.close()
+
+
+@pytest.mark.parametrize("alphabet,n_letters", [(0, 4), (1, 24)])
+def test_appends_in_pieces_sorted_and_unsorted(zone_env, alphabet, n_letters):
+    """big (sorted) and small (unsorted) appends interleaved, starting mid-tile: positions of later appends follow
+    the earlier ones, subject indices stay the append order; an N arriving late re-planes a sorted 2-bit store"""
+    zone_env["SMAFA_ZONE"] = "2"
+    rng = np.random.default_rng(99 + alphabet)
+    L = 60
+    parts = [rng.integers(0, n_letters, size=(m, L), dtype=np.uint8) for m in (5000, 3, 4100, 700, 1, 6000)]
+    if alphabet == 0:
+        parts[3][5, 7] = 4  # the first N: the store gains its third plane after two sorted appends
+    s = np.concatenate(parts)
+    q = queries_from(rng, s, 120, n_letters, 6)
+    whole = smafa_amd.SubjectStore(L, alphabet)
+    whole.push(s)
+    pieces = smafa_amd.SubjectStore(L, alphabet)
+    for p in parts:
+        pieces.push(p)
+    assert len(pieces) == len(s)
+    for D in (0, 3, 6, 30):
+        want = oracle.scan_codes(s, q, D)
+        assert whole.scan(q, max_divergence=D).tobytes() == want.tobytes(), D
+        assert pieces.scan(q, max_divergence=D).tobytes() == want.tobytes(), D
+    want1 = expected_with_k(oracle.scan_codes(s, q, L), 1)
+    assert pieces.scan(q, max_num_hits=1).tobytes() == want1.tobytes()
+    assert (pieces.get_distances(q[3]) == oracle.distances_codes(s, q[3])).all()
+    whole.close()
+    pieces.close()
+
+
+def test_sorted_and_unsorted_layouts_agree(zone_env):
+    rng = np.random.default_rng(17)
+    s = skewed_store(rng, 30000, 60, 20, families=100)
+    q = queries_from(rng, s, 200, 20, 8)
+    rows = []
+    for sort, zone in (("1", "2"), ("0", "2"), ("0", "0"), ("1", "1")):
+        zone_env["SMAFA_SORT"], zone_env["SMAFA_ZONE"] = sort, zone
+        store = smafa_amd.SubjectStore(60, 1)
+        store.push(s)
+        rows.append(store.scan(q, max_divergence=6).tobytes())
+        store.close()
+    assert len(set(rows)) == 1 and rows[0] == oracle.scan_codes(s, q, 6).tobytes()
+
+
+def test_device_launch_counts_are_exact_at_any_capacity():
+    """smafa_scan_launch's contract: *d_count = number of qualifying rows, even past cap; the first cap are stored.
+    A dense store where every pair qualifies, cap == the exact row count, cap below it, cap == 0 rows stored."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "device_capacity_worker.py")], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "device capacity ok" in r.stdout
+
+
+def test_dense_rows_through_the_lds_stage_and_spill():
+    """far more rows per workgroup and chunk than the LDS stage holds: the spill path, exact totals, every row once"""
+    rng = np.random.default_rng(3)
+    L, n = 60, 6000
+    base = rng.integers(0, 20, size=L, dtype=np.uint8)
+    s = np.tile(base, (n, 1))
+    for r in s:
+        for _ in range(rng.integers(0, 4)):
+            r[rng.integers(0, L)] = rng.integers(0, 20)
+    q = s[rng.integers(0, n, size=300)].copy()
+    store = smafa_amd.SubjectStore(L, 1)
+    store.push(s)
+    for D in (2, 6, L):
+        got = store.scan(q, max_divergence=D)
+        want = oracle.scan_codes(s, q, D)
+        assert len(got) == len(want) and got.tobytes() == want.tobytes(), D
+    store.close()
