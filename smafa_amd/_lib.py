@@ -12,7 +12,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "lib", "libsmafa_amd.so")
+# SMAFA_AMD_LIB: an alternative build of the same library (A/B runs of kernel variants: tools/variants.sh)
+LIB_PATH = os.environ.get("SMAFA_AMD_LIB") or os.path.join(_HERE, "lib", "libsmafa_amd.so")
 CLI_PATH = os.path.join(_HERE, "bin", "smafa")
 
 OK = 0

@@ -901,23 +901,59 @@ __global__ __launch_bounds__(256, 4) void scan_zone_kernel(const uint4 *__restri
 #pragma unroll
                     for (int k = 1; k < T; k++)
                         if (t == (uint32_t)k) ft = f0[k];
+#ifndef SMAFA_ZONE_VARIANT
+// A/B switches of the survivor loop (profiles/r02_zone_variants.txt).  bit 0: two survivors per iteration (two
+// dependency chains in flight): 13 % SLOWER; bit 1: the query's word from LDS, all-VGPR xors, instead of v_readlane and
+// scalar operands: 4 % slower; bit 2: opaque tile number for the rare levels (no hoisting): 6 % faster — the default.
+#define SMAFA_ZONE_VARIANT 4
+#endif
+                    auto level1 = [&](int i) -> bool {  // word 0 of the filter plane against query i of the chunk
+#if SMAFA_ZONE_VARIANT & 2
+                        const uint4 h = stage[buf][(uint32_t)i * RV];
+                        const uint32_t q0w = h.x, nu1 = BS == 1 ? h.y : h.z;
+#else
+                        const uint32_t q0w = (uint32_t)__builtin_amdgcn_readlane((int)hq0, i);
+                        const uint32_t nu1 = (uint32_t)__builtin_amdgcn_readlane((int)hnu, i);
+#endif
+                        const uint32_t u0 = __builtin_popcount(ft.x ^ q0w) + nu1;
+                        const uint32_t u1 = __builtin_popcount(ft.y ^ q0w) + nu1;
+                        const uint32_t u2 = __builtin_popcount(ft.z ^ q0w) + nu1;
+                        const uint32_t u3 = __builtin_popcount(ft.w ^ q0w) + nu1;
+                        return __ballot((int32_t)(or3(u0, u1, u2) | u3) < 0) != 0ull;
+                    };
                     while (m != 0ull) {
+#if SMAFA_ZONE_VARIANT & 1
+                        // two survivors per iteration: two independent dependency chains in flight per wave
+                        const int ia = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        const int ib = m != 0ull ? __builtin_ctzll(m) : ia;  // no second survivor: ia twice, no branch
+                        m &= m - 1ull;
+                        const bool pa = level1(ia), pb = level1(ib);
+                        const unsigned long long todo = (pa ? 1ull << ia : 0ull) | (pb ? 1ull << ib : 0ull);
+                        if (todo == 0ull) continue;
+                        m |= todo & (todo - 1ull);  // both passed (very rare): the second one goes round again
+                        const int i = __builtin_ctzll(todo);
+#else
                         const int i = __builtin_ctzll(m);
                         m &= m - 1ull;
                         // ---- level 1: word 0 of the filter plane
-                        const uint32_t q0w = (uint32_t)__builtin_amdgcn_readlane((int)hq0, i);
+                        if (!level1(i)) continue;
+#endif
                         const uint32_t nu = (uint32_t)__builtin_amdgcn_readlane((int)hnu, i);
-                        const uint32_t u0 = __builtin_popcount(ft.x ^ q0w) + nu;
-                        const uint32_t u1 = __builtin_popcount(ft.y ^ q0w) + nu;
-                        const uint32_t u2 = __builtin_popcount(ft.z ^ q0w) + nu;
-                        const uint32_t u3 = __builtin_popcount(ft.w ^ q0w) + nu;
-                        if (__ballot((int32_t)(or3(u0, u1, u2) | u3) < 0) == 0ull) continue;
+#if SMAFA_ZONE_VARIANT & 4
+                        // the rare levels get the tile number through an opaque copy: otherwise the compiler hoists
+                        // their ~25 address computations out of this loop into the per-tile path every chunk pays for
+                        uint32_t tile_r = tile;
+                        asm volatile("" : "+s"(tile_r));
+#else
+                        const uint32_t tile_r = tile;
+#endif
                         // ---- level 2 (rare): the filter plane folded over all its words, words 1.. from L2/HBM
                         uint32_t qw[RS];
                         read_record(&stage[buf][(uint32_t)i * RV], qw);
                         uint32_t m0 = ft.x ^ qw[0], m1 = ft.y ^ qw[0], m2 = ft.z ^ qw[0], m3 = ft.w ^ qw[0];
                         if (W > 1) {
-                            const uint4 *src = planes + (size_t)tile * (PS * W * 64) + (FP * W) * 64 + lane;
+                            const uint4 *src = planes + (size_t)tile_r * (PS * W * 64) + (FP * W) * 64 + lane;
 #pragma unroll
                             for (int w = 1; w < W; w++) {
                                 const uint4 v = src[w * 64];
@@ -937,7 +973,7 @@ __global__ __launch_bounds__(256, 4) void scan_zone_kernel(const uint4 *__restri
                         }
                         // ---- level 3: all planes, exactly
                         passes++;
-                        stream_compare(tile, qw, qc + (uint32_t)i);
+                        stream_compare(tile_r, qw, qc + (uint32_t)i);
                     }
                 }
                 filter_on = passes * 4u <= nqc;
