@@ -92,6 +92,13 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len);
 /* push_encoding x n (src/lib.rs:91-111): packs n rows of code bytes into the HBM bit-plane block.
  * The host buffer is borrowed for the call only. */
 int smafa_db_append(smafa_db *db, const uint8_t *codes, uint64_t n);
+/* The packed store file: a resident store saved exactly as it lies in HBM — layout tables, bit-plane
+ * tiles, subject order, zone words — so that loading it is a memory map and three host-to-device copies instead of the
+ * postcard decode of src/lib.rs:208-218 (<= 46 bytes of varints per subject) plus a re-pack.  The file starts with
+ * varint(3): the reference rejects it with its own "Unsupported db file version" panic (src/lib.rs:214-217).
+ * Written by `smafa makedb --packed`, accepted wherever a DB file is (smafa_query, smafa_dbfile_read). */
+int smafa_db_save(smafa_db *db, const char *path);
+int smafa_db_load(smafa_db **out, int device, const char *path);
 int smafa_db_info(const smafa_db *db, smafa_db_info_t *info);
 /* Launch on a caller-owned HIP stream (hipStream_t as void*) instead of the handle's own; NULL restores it. */
 int smafa_db_set_stream(smafa_db *db, void *hip_stream);
@@ -188,10 +195,20 @@ void smafa_free(void *p);
 /* ------------------------------------------- drivers: the crate's pub fns */
 /* makedb(subject_fasta, db_path) — src/lib.rs:137-165.  Host only (no GPU needed). */
 int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet);
+/* makedb with the packed store file as output: the subjects are packed on `device` (the layout is the one a query
+ * would build) and saved with smafa_db_save.  Needs a GPU; plain smafa_makedb does not. */
+int smafa_makedb_packed(const char *subject_fasta, const char *db_path, int alphabet, int device);
 /* query(db_path, query_fasta, max_divergence, max_num_hits, limit_per_sequence) — src/lib.rs:198-325.
  * Options use SMAFA_NONE for None.  TSV rows go to out_fd (the reference prints to stdout). */
 int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_divergence, uint32_t max_num_hits,
                 uint32_t limit_per_sequence, int out_fd, int device);
+/* The same query spread over several GPUs of one node by ONE process ("queries sharded across the handle's
+ * devices internally"): one handle per entry of `devices` (an entry may repeat: several handles on one GPU), the store
+ * replicated on each, every chunk of queries cut into ndev contiguous blocks scanned by one host thread per handle,
+ * rows printed in block order.  The loop being sharded is src/lib.rs:232-318, which carries no state between queries
+ * but the running query number, so the bytes written do not depend on ndev.  No collective, no torch. */
+int smafa_query_multi(const char *db_path, const char *query_fasta, uint32_t max_divergence, uint32_t max_num_hits,
+                      uint32_t limit_per_sequence, int out_fd, const int *devices, int ndev);
 /* cluster(input_fasta, max_divergence, print_stream) — src/cluster.rs:13-94. */
 int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet);
 /* The same clustering spread over `world` processes, one GPU each (cluster mode): every rank reads

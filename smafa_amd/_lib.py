@@ -24,11 +24,11 @@ ALPHABET_NT, ALPHABET_AA = 0, 1
 # every symbol include/smafa_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "smafa_last_error", "smafa_device_count", "smafa_set_verbosity", "smafa_encode", "smafa_decode",
-    "smafa_db_create", "smafa_db_append", "smafa_db_info", "smafa_db_set_stream", "smafa_db_destroy",
+    "smafa_db_create", "smafa_db_append", "smafa_db_save", "smafa_db_load", "smafa_db_info", "smafa_db_set_stream", "smafa_db_destroy",
     "smafa_scan_hits", "smafa_distances", "smafa_qset_create", "smafa_qset_destroy", "smafa_scan_launch",
     "smafa_sync", "smafa_last_scan_ms", "smafa_last_scan_plan", "smafa_last_scan_kernel", "smafa_build_id", "smafa_hbm_read_probe", "smafa_set_query_block", "smafa_set_prefilter", "smafa_select_rows", "smafa_write_rows",
     "smafa_dbfile_write", "smafa_dbfile_read", "smafa_fastx_load", "smafa_free",
-    "smafa_makedb", "smafa_query", "smafa_cluster", "smafa_cluster_sharded", "smafa_count",
+    "smafa_makedb", "smafa_makedb_packed", "smafa_query", "smafa_query_multi", "smafa_cluster", "smafa_cluster_sharded", "smafa_count",
 ]
 
 
@@ -80,6 +80,9 @@ def lib() -> C.CDLL:
     l.smafa_decode.argtypes = [C.c_int, vp, C.c_uint64, vp]
     l.smafa_db_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_uint32]
     l.smafa_db_append.argtypes = [vp, vp, C.c_uint64]
+    l.smafa_db_save.argtypes = [vp, C.c_char_p]
+    l.smafa_db_load.argtypes = [C.POINTER(vp), C.c_int, C.c_char_p]
+    l.smafa_makedb_packed.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
     l.smafa_db_info.argtypes = [vp, C.POINTER(DbInfo)]
     l.smafa_db_set_stream.argtypes = [vp, vp]
     l.smafa_db_destroy.argtypes = [vp]
@@ -108,6 +111,7 @@ def lib() -> C.CDLL:
     l.smafa_free.restype = None
     l.smafa_makedb.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     l.smafa_query.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+    l.smafa_query_multi.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.c_int]
     l.smafa_cluster.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_int]
     l.smafa_cluster_sharded.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                                         ALLGATHER_FN, vp]

@@ -95,6 +95,19 @@ class SubjectStore:
         self.alphabet = alphabet
         check(lib().smafa_db_create(C.byref(self._h), device, alphabet, self.seq_len))
 
+    @classmethod
+    def load(cls, path: str, device: int = 0) -> "SubjectStore":
+        """a store from a packed store file (smafa_db_load): mmap + three host-to-device copies"""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        check(lib().smafa_db_load(C.byref(self._h), device, os.fsencode(path)))
+        info = self.info()
+        self.seq_len, self.alphabet = int(info.seq_len), int(info.alphabet)
+        return self
+
+    def save(self, path: str) -> None:
+        check(lib().smafa_db_save(self._h, os.fsencode(path)))
+
     # push_encoding x n (src/lib.rs:91-111)
     def push(self, codes: np.ndarray) -> None:
         c = np.ascontiguousarray(codes, dtype=np.uint8)
@@ -244,9 +257,20 @@ def makedb(subject_fasta: str, db_path: str, alphabet: int = ALPHABET_NT) -> Non
     check(lib().smafa_makedb(os.fsencode(subject_fasta), os.fsencode(db_path), alphabet))
 
 
+def makedb_packed(subject_fasta: str, db_path: str, alphabet: int = ALPHABET_NT, device: int = 0) -> None:
+    """makedb writing the packed store file (needs a GPU: the subjects are packed on `device`)."""
+    check(lib().smafa_makedb_packed(os.fsencode(subject_fasta), os.fsencode(db_path), alphabet, device))
+
+
 def query(db_path: str, query_fasta: str, max_divergence: Optional[int] = None, max_num_hits: Optional[int] = None,
-          limit_per_sequence: Optional[int] = None, out_fd: int = 1, device: int = 0) -> None:
-    """query(db_path, query_fasta, max_divergence, max_num_hits, limit_per_sequence) — src/lib.rs:198-325."""
+          limit_per_sequence: Optional[int] = None, out_fd: int = 1, device: int = 0, devices=None) -> None:
+    """query(db_path, query_fasta, max_divergence, max_num_hits, limit_per_sequence) — src/lib.rs:198-325.
+    `devices`: a list of GPU ordinals (entries may repeat) = one process, one handle and host thread per entry."""
+    if devices is not None:
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        check(lib().smafa_query_multi(os.fsencode(db_path), os.fsencode(query_fasta), _opt(max_divergence),
+                                      _opt(max_num_hits), _opt(limit_per_sequence), out_fd, arr, len(devices)))
+        return
     check(lib().smafa_query(os.fsencode(db_path), os.fsencode(query_fasta), _opt(max_divergence), _opt(max_num_hits),
                             _opt(limit_per_sequence), out_fd, device))
 

@@ -23,10 +23,21 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
 void warm_device(int device);
 // Forget the subjects but keep the handle's device memory, stream and scratch (cluster's per-batch candidate store).
 int db_clear(smafa_db *db);
+class PackedStore;
+// Where the drivers read a subject's symbols from: code rows in host memory (a decoded version-2 file) or the mapped
+// bit-plane tiles of a packed store file (host/packed.cpp), decoded row by row — only hit rows are ever read.
+struct SubjectRows {
+    const uint8_t *codes = nullptr;
+    const PackedStore *packed = nullptr;
+    uint32_t L = 0;
+    void get(uint64_t j, uint8_t *out) const;  // L code bytes of subject j
+};
 // selection rules of src/lib.rs:241-315 (see smafa_select_rows in the public header)
 int select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint64_t n_subjects,
-                const uint8_t *subject_codes, uint32_t seq_len, uint32_t max_div, uint32_t max_num_hits,
-                uint32_t limit_per_sequence, std::vector<smafa_hit> &rows);
+                const SubjectRows &subjects, uint32_t max_div, uint32_t max_num_hits, uint32_t limit_per_sequence,
+                std::vector<smafa_hit> &rows);
+// a store handle whose HBM image comes straight from a mapped packed store file
+int db_load_packed(smafa_db **out, int device, const PackedStore &pk);
 
 // stderr logging of the drivers (host/common.cpp): level 1 = info, 2 = debug
 int verbosity();

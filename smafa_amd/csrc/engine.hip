@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "host/packed.h"
 #include "kernels.hip.h"
 
 namespace smafa {
@@ -963,6 +964,41 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
     return SMAFA_OK;
 }
 
+// A handle whose HBM image is a mapped packed store file: no decode, no pack kernel — three copies.
+int db_load_packed(smafa_db **out, int device, const PackedStore &pk) {
+    if (!out) return set_error(SMAFA_ERR_INVALID, "db_load_packed: out is NULL");
+    int rc = smafa_db_create(out, device, (int)pk.h.alphabet, pk.h.seq_len);
+    if (rc) return rc;
+    smafa_db *db = *out;
+    auto fail = [&](int code) {
+        smafa_db_destroy(db);
+        *out = nullptr;
+        return code;
+    };
+    db->P = pk.h.planes;
+    db->perm.assign(pk.perm, pk.perm + (size_t)db->W * 32);
+    db->tab.assign(pk.tab, pk.tab + (size_t)db->L * 32);
+    rc = db->d_perm.ensure(db->perm.size() * sizeof(uint16_t));
+    if (!rc) rc = db->d_tab.ensure(db->tab.size());
+    if (rc) return fail(rc);
+    hipError_t e = hipMemcpyAsync(db->d_perm.p, db->perm.data(), db->perm.size() * sizeof(uint16_t), hipMemcpyHostToDevice, db->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db->d_tab.p, db->tab.data(), db->tab.size(), hipMemcpyHostToDevice, db->stream);
+    db->layout_set = true;
+    if (e == hipSuccess && pk.h.n > 0) {
+        rc = reserve_tiles(db, pk.h.n_tiles);
+        if (rc) return fail(rc);
+        e = hipMemcpyAsync(db->d_planes, pk.planes, pk.h.n_tiles * db->tile_words() * sizeof(uint32_t), hipMemcpyHostToDevice, db->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(db->d_order, pk.order, pk.h.n_tiles * kWaveTile * sizeof(uint32_t), hipMemcpyHostToDevice, db->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(db->d_zone, pk.zone, pk.h.n_tiles * sizeof(uint4), hipMemcpyHostToDevice, db->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
+    if (e != hipSuccess) return fail(set_error(SMAFA_ERR_DEVICE, "loading the packed store failed: %s", hipGetErrorString(e)));
+    db->n = pk.h.n;
+    for (uint64_t r = 0; r < pk.h.n_runs; r++) db->runs.push_back({pk.runs[2 * r], pk.runs[2 * r + 1] != 0});
+    db->generation++;
+    return SMAFA_OK;
+}
+
 }  // namespace smafa
 
 // ------------------------------------------------------------------------------------- C ABI
@@ -1048,6 +1084,47 @@ int smafa_db_append(smafa_db *db, const uint8_t *codes, uint64_t n) {
         for (DevBuf *b : {&db->upload, &db->keys_a, &db->keys_b, &db->idx_a, &db->idx_b, &db->sort_tmp}) b->release();
     }
     return SMAFA_OK;
+}
+
+int smafa_db_save(smafa_db *db, const char *path) {
+    if (!db || !path) return set_error(SMAFA_ERR_INVALID, "smafa_db_save: NULL argument");
+    int rc = use_device(db);
+    if (rc) return rc;
+    if (!db->layout_set) {  // an empty store has no layout yet: give it the default one
+        rc = choose_layout(db, nullptr, 0);
+        if (rc) return rc;
+    }
+    PackedHeader h{};
+    h.alphabet = (uint32_t)db->alphabet;
+    h.seq_len = db->L;
+    h.planes = db->P;
+    h.words = db->W;
+    h.n = db->n;
+    h.n_tiles = (db->n + kWaveTile - 1) / kWaveTile;
+    h.n_runs = db->runs.size();
+    std::vector<uint32_t> planes(h.n_tiles * db->tile_words()), order(h.n_tiles * kWaveTile);
+    std::vector<uint4> zone(h.n_tiles);
+    if (h.n_tiles) {
+        HIP_TRY(hipMemcpyAsync(planes.data(), db->d_planes, planes.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, db->stream));
+        HIP_TRY(hipMemcpyAsync(order.data(), db->d_order, order.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, db->stream));
+        HIP_TRY(hipMemcpyAsync(zone.data(), db->d_zone, zone.size() * sizeof(uint4), hipMemcpyDeviceToHost, db->stream));
+        HIP_TRY(hipStreamSynchronize(db->stream));
+    }
+    std::vector<uint64_t> runs;
+    for (const smafa_db::Run &r : db->runs) {
+        runs.push_back(r.rows);
+        runs.push_back(r.sorted ? 1u : 0u);
+    }
+    return write_packed_file(path, h, db->perm.data(), db->tab.data(), runs.data(), order.data(), zone.data(), planes.data());
+}
+
+int smafa_db_load(smafa_db **out, int device, const char *path) {
+    if (!out || !path) return set_error(SMAFA_ERR_INVALID, "smafa_db_load: NULL argument");
+    *out = nullptr;
+    PackedStore pk;
+    int rc = pk.open(path);
+    if (rc) return rc;
+    return db_load_packed(out, device, pk);
 }
 
 int smafa_db_info(const smafa_db *db, smafa_db_info_t *info) {

@@ -21,10 +21,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
 #include "../engine.h"
+#include "packed.h"
 
 namespace smafa {
 
@@ -196,6 +198,40 @@ int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t
     size_t pos = 0;
     uint64_t version = 0;
     if (!get_varint(buf.data(), 4, pos, 5, version)) return set_error(SMAFA_ERR_FORMAT, "DeserializeUnexpectedEnd");
+    if (is_packed_file(buf.data(), buf.size())) {  // version 3, kind 2: bit-plane tiles (host/packed.cpp): decode every row
+        PackedStore pk;
+        rc = pk.open(path);
+        if (rc) return rc;
+        const uint64_t cnt = pk.h.n, len = pk.h.seq_len;
+        uint8_t *out = (uint8_t *)malloc(std::max<size_t>(cnt * len, 1));
+        if (!out) return set_error(SMAFA_ERR_IO, "out of memory");
+        const unsigned T = cnt >= (1u << 16) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        std::vector<int> rcs(T, SMAFA_OK);
+        std::vector<std::string> msgs(T);
+        auto work = [&](unsigned t) {
+            for (uint64_t j = cnt * t / T, e = cnt * (t + 1) / T; j < e && rcs[t] == SMAFA_OK; j++) {
+                rcs[t] = pk.row(j, out + (size_t)j * len);
+                if (rcs[t]) msgs[t] = smafa_last_error();
+            }
+        };
+        if (T == 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < T; t++) pool.emplace_back(work, t);
+            for (auto &th : pool) th.join();
+        }
+        for (unsigned t = 0; t < T; t++)
+            if (rcs[t]) {
+                free(out);
+                return set_error(rcs[t], "%s", msgs[t].c_str());
+            }
+        *alphabet = (int)pk.h.alphabet;
+        *codes = out;
+        *n = cnt;
+        *seq_len = (uint32_t)len;
+        return SMAFA_OK;
+    }
     if (version == 3) {
         uint64_t a, cnt, len;
         if (!get_varint(buf.data(), buf.size(), pos, 5, a) || !get_varint(buf.data(), buf.size(), pos, 10, cnt) ||

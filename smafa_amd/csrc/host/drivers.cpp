@@ -20,6 +20,7 @@
 
 #include "../engine.h"
 #include "fastx.h"
+#include "packed.h"
 
 namespace smafa {
 
@@ -72,11 +73,12 @@ void append_decoded(std::string &s, int alphabet, const uint8_t *codes, uint32_t
 
 // "{query}\t{subject}\t{distance}\t{subject string}\n" per row (src/lib.rs:292,310), written to fd in order.  Big row
 // lists are formatted by several threads, each into its own buffer over a contiguous slice of the rows.
-int write_rows_text(const smafa_hit *rows, size_t n, const uint8_t *codes, uint32_t L, int alphabet, uint32_t q_base,
-                    int fd) {
+int write_rows_text(const smafa_hit *rows, size_t n, const SubjectRows &subjects, int alphabet, uint32_t q_base, int fd) {
+    const uint32_t L = subjects.L;
     auto format = [&](size_t lo, size_t hi, std::string &text) {
         text.clear();
         text.reserve((hi - lo) * ((size_t)L + 24));
+        std::vector<uint8_t> row(L);
         for (size_t i = lo; i < hi; i++) {
             const smafa_hit &h = rows[i];
             append_u32(text, q_base + h.query);
@@ -85,7 +87,8 @@ int write_rows_text(const smafa_hit *rows, size_t n, const uint8_t *codes, uint3
             text.push_back('\t');
             append_u32(text, h.dist);
             text.push_back('\t');
-            append_decoded(text, alphabet, codes + (size_t)h.subject * L, L);
+            subjects.get(h.subject, row.data());
+            append_decoded(text, alphabet, row.data(), L);
             text.push_back('\n');
         }
     };
@@ -241,10 +244,42 @@ int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet) {
     return rc;
 }
 
+// makedb with the packed store file as output (host/packed.cpp): the same parse + encode, then the subjects are packed on
+// the device exactly as `query` would pack them, and the resident store is saved.
+int smafa_makedb_packed(const char *subject_fasta, const char *db_path, int alphabet, int device) {
+    if (!subject_fasta || !db_path) return set_error(SMAFA_ERR_INVALID, "smafa_makedb_packed: NULL path");
+    if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
+        return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
+    std::thread warm(warm_device, device);
+    BulkRecords recs;
+    int rc = load_records_bulk(subject_fasta, alphabet, false, recs);  // src/lib.rs:143-152
+    warm.join();
+    if (rc) return rc;
+    if (recs.err_kind == 3) return set_error(SMAFA_ERR_PANIC, "Cannot add empty sequence to WindowSet");
+    if (recs.err_kind == 1) return set_error(SMAFA_ERR_PANIC, "%s", recs.err_msg.c_str());
+    if (recs.err_kind == 2)
+        return set_error(SMAFA_ERR_PANIC, "WindowSet seq length is %zu, got a new sequence of length %zu", recs.L, recs.err_len);
+    if (recs.err_kind == 4) return set_error(SMAFA_ERR_FORMAT, "%s", recs.err_msg.c_str());
+    if (recs.n == 0) return set_error(SMAFA_ERR_INVALID, "a packed store needs at least one sequence (its length fixes the layout)");
+    if (recs.L > 0xffffffffull) return set_error(SMAFA_ERR_INVALID, "sequence too long");
+    log_line(1, "Encoding of %llu sequences complete, packing on device %d and writing %s", (unsigned long long)recs.n, device, db_path);
+    DbGuard guard;
+    rc = smafa_db_create(&guard.db, device, alphabet, (uint32_t)recs.L);
+    if (!rc) rc = smafa_db_append(guard.db, recs.codes.data(), recs.n);
+    if (!rc) rc = smafa_db_save(guard.db, db_path);
+    if (rc == SMAFA_OK) log_line(1, "DB file written");
+    return rc;
+}
+
 // -------------------------------------------------------------------------------------- query
-int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_divergence, uint32_t max_num_hits,
-                uint32_t limit_per_sequence, int out_fd, int device) {
+// One process, one handle per entry of `devices` (entries may repeat: several handles on one GPU), the store replicated
+// on each.  The query loop of the reference carries no state between records except the running query number
+// (src/lib.rs:232-318), so every chunk of queries is cut into ndev contiguous blocks, block g is scanned and selected by
+// host thread g on handle g, and the blocks' rows are printed in block order: the output does not depend on ndev.
+int smafa_query_multi(const char *db_path, const char *query_fasta, uint32_t max_divergence, uint32_t max_num_hits,
+                      uint32_t limit_per_sequence, int out_fd, const int *devices, int ndev) {
     if (!db_path || !query_fasta) return set_error(SMAFA_ERR_INVALID, "smafa_query: NULL path");
+    if (!devices || ndev < 1 || ndev > 64) return set_error(SMAFA_ERR_INVALID, "smafa_query_multi: 1 to 64 devices expected");
     int alphabet = 0;
     uint64_t n = 0;
     uint32_t L = 0;
@@ -252,63 +287,131 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
     uint8_t *codes = nullptr;
     const double t_start = now_seconds();
     struct Warm {  // device bring-up overlaps the file read and decode; joined before the first device call or return
-        std::thread t;
-        explicit Warm(int device) : t(warm_device, device) {}
-        ~Warm() { if (t.joinable()) t.join(); }
-    } warm(device);
+        std::vector<std::thread> t;
+        Warm(const int *devices, int ndev) {
+            for (int g = 0; g < ndev; g++) {
+                bool seen = false;
+                for (int h = 0; h < g; h++) seen = seen || devices[h] == devices[g];
+                if (!seen) t.emplace_back(warm_device, devices[g]);
+            }
+        }
+        void join() {
+            for (auto &th : t)
+                if (th.joinable()) th.join();
+        }
+        ~Warm() { join(); }
+    } warm(devices, ndev);
     log_line(1, "Decoding db file \"%s\"", db_path);  // src/lib.rs:206
-    int rc = smafa_dbfile_read(db_path, &alphabet, &codes, &n, &L);  // src/lib.rs:208-218
-    if (rc) return rc;
-    codes_guard.p = codes;
-    log_line(2, "db decoded: %llu sequences of length %u in %.2f s", (unsigned long long)n, L, now_seconds() - t_start);
+    PackedStore pk;  // a packed store file is mapped, not decoded (host/packed.cpp)
+    bool packed = false;
+    {
+        uint8_t head[8] = {0};
+        FILE *f = fopen(db_path, "rb");
+        if (f) {
+            const size_t got = fread(head, 1, sizeof head, f);
+            fclose(f);
+            packed = is_packed_file(head, got);
+        }
+    }
+    int rc;
+    if (packed) {
+        rc = pk.open(db_path);
+        if (rc) return rc;
+        alphabet = (int)pk.h.alphabet;
+        n = pk.h.n;
+        L = pk.h.seq_len;
+    } else {
+        rc = smafa_dbfile_read(db_path, &alphabet, &codes, &n, &L);  // src/lib.rs:208-218
+        if (rc) return rc;
+        codes_guard.p = codes;
+    }
+    SubjectRows subjects;
+    subjects.codes = codes;
+    subjects.packed = packed ? &pk : nullptr;
+    subjects.L = L;
+    log_line(2, "db %s: %llu sequences of length %u in %.2f s", packed ? "mapped" : "decoded", (unsigned long long)n, L,
+             now_seconds() - t_start);
 
     FastxReader reader;
     rc = reader.open(query_fasta);  // src/lib.rs:221
     if (rc) return rc;
 
-    DbGuard guard;
+    std::vector<DbGuard> guards((size_t)ndev);
+    // run fn(g) for every handle on its own host thread (HIP's current device is per thread); first failure in handle order
+    auto on_every_handle = [&](auto &&fn) -> int {
+        std::vector<int> rcs((size_t)ndev, SMAFA_OK);
+        std::vector<std::string> msgs((size_t)ndev);
+        auto body = [&](int g) {
+            rcs[g] = fn(g);
+            if (rcs[g]) msgs[g] = smafa_last_error();  // the error text is per thread: carry it over
+        };
+        if (ndev == 1) {
+            body(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (int g = 0; g < ndev; g++) pool.emplace_back(body, g);
+            for (auto &th : pool) th.join();
+        }
+        for (int g = 0; g < ndev; g++)
+            if (rcs[g]) return set_error(rcs[g], "%s", msgs[g].c_str());
+        return SMAFA_OK;
+    };
     if (n > 0) {
-        warm.t.join();
+        warm.join();
         const double t0 = now_seconds();
-        rc = smafa_db_create(&guard.db, device, alphabet, L);
+        rc = on_every_handle([&](int g) -> int {
+            if (packed) return db_load_packed(&guards[g].db, devices[g], pk);
+            int r = smafa_db_create(&guards[g].db, devices[g], alphabet, L);
+            if (!r) r = smafa_db_append(guards[g].db, codes, n);
+            return r;
+        });
         if (rc) return rc;
-        rc = smafa_db_append(guard.db, codes, n);
-        if (rc) return rc;
-        log_line(2, "subject store packed into HBM on device %d in %.2f s", device, now_seconds() - t0);
+        log_line(2, "subject store packed into HBM on %d handle(s) in %.2f s", ndev, now_seconds() - t0);
     }
     log_line(1, "Querying ..");  // src/lib.rs:230
-    double t_scan = 0, t_select = 0;
+    double t_scan = 0;
 
     const bool kmode = max_num_hits != SMAFA_NONE && max_num_hits != 1;  // src/lib.rs:224
     // the device bound: k-th smallest distance (k = 1: the minimum); no k bound when k exceeds the store
     const uint32_t dev_k = !kmode ? 1u : (max_num_hits == 0 || max_num_hits > (uint32_t)n) ? SMAFA_NONE : max_num_hits;
     // rows per query are bounded by the store size when nothing else bounds them
     const bool unbounded = max_divergence == SMAFA_NONE && dev_k == SMAFA_NONE;
-    const uint64_t chunk_queries = unbounded ? std::max<uint64_t>(1, (16ull << 20) / std::max<uint64_t>(n, 1)) : 65536;
+    const uint64_t chunk_queries =
+        (unbounded ? std::max<uint64_t>(1, (16ull << 20) / std::max<uint64_t>(n, 1)) : 65536) * (uint64_t)ndev;
 
     std::vector<uint8_t> qcodes;
-    std::vector<smafa_hit> hits, rows;
     uint32_t query_number = 0;  // src/lib.rs:231
     uint64_t in_chunk = 0;
     int pending = SMAFA_OK;  // error to report after the rows already due have been printed
     std::string pending_msg;
 
     // scan + select + print `count` queries whose code rows start at qptr; query_number already counts them
+    std::vector<std::vector<smafa_hit>> block_hits((size_t)ndev), block_rows((size_t)ndev);
     auto run_chunk = [&](const uint8_t *qptr, uint64_t count) -> int {
         if (count == 0) return SMAFA_OK;
-        hits.clear();
-        double t0 = now_seconds();
-        if (n > 0) {
-            int r = scan_to_host(guard.db, qptr, count, max_divergence, dev_k, hits);
+        const double t0 = now_seconds();
+        // block g = queries [count*g/ndev, count*(g+1)/ndev) of the chunk, on handle g
+        int r = on_every_handle([&](int g) -> int {
+            const uint64_t lo = count * (uint64_t)g / (uint64_t)ndev, hi = count * (uint64_t)(g + 1) / (uint64_t)ndev;
+            block_hits[g].clear();
+            block_rows[g].clear();
+            if (hi == lo) return SMAFA_OK;
+            if (n > 0) {
+                int rr = scan_to_host(guards[g].db, qptr + (size_t)lo * L, hi - lo, max_divergence, dev_k, block_hits[g]);
+                if (rr) return rr;
+            }
+            return select_rows(block_hits[g].data(), block_hits[g].size(), hi - lo, n, subjects, max_divergence, max_num_hits,
+                               limit_per_sequence, block_rows[g]);
+        });
+        t_scan += now_seconds() - t0;
+        if (r) return r;
+        for (int g = 0; g < ndev; g++) {
+            const uint64_t lo = count * (uint64_t)g / (uint64_t)ndev;
+            r = write_rows_text(block_rows[g].data(), block_rows[g].size(), subjects, alphabet,
+                                query_number - (uint32_t)count + (uint32_t)lo, out_fd);
             if (r) return r;
         }
-        t_scan += now_seconds() - t0;
-        t0 = now_seconds();
-        int r = select_rows(hits.data(), hits.size(), count, n, codes, L, max_divergence, max_num_hits,
-                            limit_per_sequence, rows);
-        if (r) return r;
-        t_select += now_seconds() - t0;
-        return write_rows_text(rows.data(), rows.size(), codes, L, alphabet, query_number - (uint32_t)count, out_fd);
+        return SMAFA_OK;
     };
     auto flush = [&]() -> int {
         int r = run_chunk(qcodes.data(), in_chunk);
@@ -382,9 +485,14 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
     int frc = flush();
     if (frc) return frc;
     if (pending != SMAFA_OK) return set_error(pending, "%s", pending_msg.c_str());
-    log_line(2, "%u queries: scans %.2f s, selection %.2f s", query_number, t_scan, t_select);
+    log_line(2, "%u queries: scans + selection %.2f s on %d handle(s)", query_number, t_scan, ndev);
     log_line(1, "Querying complete, took %llu seconds", (unsigned long long)(now_seconds() - t_start));  // src/lib.rs:320-323
     return SMAFA_OK;
+}
+
+int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_divergence, uint32_t max_num_hits,
+                uint32_t limit_per_sequence, int out_fd, int device) {
+    return smafa_query_multi(db_path, query_fasta, max_divergence, max_num_hits, limit_per_sequence, out_fd, &device, 1);
 }
 
 // ------------------------------------------------------------------------------------ cluster
@@ -662,7 +770,10 @@ int smafa_write_rows(const smafa_hit *rows, uint64_t n_rows, const uint8_t *subj
         if (rows[i].subject >= n_subjects)
             return set_error(SMAFA_ERR_INVALID, "row %llu names subject %u of %llu", (unsigned long long)i, rows[i].subject,
                              (unsigned long long)n_subjects);
-    return write_rows_text(rows, n_rows, subject_codes, seq_len, alphabet, query_offset, out_fd);
+    SubjectRows subjects;
+    subjects.codes = subject_codes;
+    subjects.L = seq_len;
+    return write_rows_text(rows, n_rows, subjects, alphabet, query_offset, out_fd);
 }
 
 // -------------------------------------------------------------------------------------- count

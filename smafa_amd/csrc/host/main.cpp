@@ -6,7 +6,9 @@
 //   cluster -i/--input FILE  -d/--max-divergence INT
 //   count   -i/--input FILE...
 // plus -v/--verbose and --quiet (logging only; results are the only thing on stdout).
-// Additions of this build: --device N (query, cluster), --alphabet nt|aa (makedb, cluster).
+// Additions of this build: --device N (query, cluster), --gpus N (query: GPUs 0..N-1, one handle and host thread
+// each; the output does not depend on N), --devices a,b,.. (query: explicit list, entries may repeat),
+// --alphabet nt|aa (makedb, cluster), --packed (makedb: the packed store file, host/packed.cpp).
 // Exit status: 0 ok, 101 where the reference panics (a Rust panic exits 101), 1 other failures, 2 usage.
 #include <cstdio>
 #include <cstdlib>
@@ -27,9 +29,10 @@ static int usage(const char *msg) {
             "  query    Search a database. See query --help for more information about output format.\n"
             "  cluster  Cluster sequences by similarity\n"
             "  count    Print the number of reads/bases in a possibly gzipped FASTX file\n\n"
-            "makedb  -i, --input <FILE>  -d, --database <FILE>  [--alphabet nt|aa]\n"
+            "makedb  -i, --input <FILE>  -d, --database <FILE>  [--alphabet nt|aa] [--packed [--device <N>]]\n"
+            "        --packed: write the store as it lies in GPU memory (needs a GPU; loads without decoding)\n"
             "query   -d, --database <FILE>  -q, --query <FILE>  [--max-divergence <INT>] [--max-num-hits <INT>]\n"
-            "        [--limit-per-sequence <INT>] [--device <N>]\n"
+            "        [--limit-per-sequence <INT>] [--device <N> | --gpus <N> | --devices <a,b,..>]\n"
             "        Output columns (tab-separated): query number (0-indexed), subject number (0-indexed),\n"
             "        divergence, subject sequence (dashes and degenerate bases shown as N)\n"
             "cluster -i, --input <FILE>  -d, --max-divergence <INT>  [--alphabet nt|aa] [--device <N>]\n"
@@ -57,7 +60,8 @@ int main(int argc, char **argv) {
     const char *input = nullptr, *database = nullptr, *query = nullptr;
     std::vector<const char *> count_paths;
     uint32_t max_div = SMAFA_NONE, max_hits = SMAFA_NONE, limit = SMAFA_NONE, device = 0;
-    bool have_max_div = false;
+    bool have_max_div = false, packed = false;
+    std::vector<int> devices;  // query: more than one handle
     int alphabet = SMAFA_ALPHABET_NT;
     int verbosity = 1;  // the reference logs at info level unless told otherwise (bird_tool_utils set_log_level)
     if (const char *e = getenv("SMAFA_LOG")) verbosity = atoi(e);
@@ -87,6 +91,29 @@ int main(int argc, char **argv) {
             if (!parse_u32(value(), &limit)) return usage("--limit-per-sequence needs an unsigned integer");
         } else if (a == "--device") {
             if (!parse_u32(value(), &device)) return usage("--device needs an unsigned integer");
+        } else if (a == "--packed") {
+            packed = true;
+        } else if (a == "--gpus") {
+            uint32_t g = 0;
+            if (!parse_u32(value(), &g) || g < 1 || g > 64) return usage("--gpus needs a count between 1 and 64");
+            devices.clear();
+            for (uint32_t d = 0; d < g; d++) devices.push_back((int)d);
+        } else if (a == "--devices") {
+            const char *v = value();
+            if (!v) return usage("--devices needs a comma-separated list");
+            devices.clear();
+            std::string tok;
+            for (const char *c = v;; c++) {
+                if (*c == ',' || *c == 0) {
+                    uint32_t d = 0;
+                    if (!parse_u32(tok.c_str(), &d)) return usage("--devices needs a comma-separated list of GPU ordinals");
+                    devices.push_back((int)d);
+                    tok.clear();
+                    if (*c == 0) break;
+                } else {
+                    tok.push_back(*c);
+                }
+            }
         } else if (a == "--alphabet") {
             const char *v = value();
             if (v && !strcmp(v, "nt")) alphabet = SMAFA_ALPHABET_NT;
@@ -107,10 +134,11 @@ int main(int argc, char **argv) {
     int rc;
     if (cmd == "makedb") {
         if (!input || !database) return usage("makedb needs --input and --database");
-        rc = smafa_makedb(input, database, alphabet);
+        rc = packed ? smafa_makedb_packed(input, database, alphabet, (int)device) : smafa_makedb(input, database, alphabet);
     } else if (cmd == "query") {
         if (!database || !query) return usage("query needs --database and --query");
-        rc = smafa_query(database, query, max_div, max_hits, limit, 1, (int)device);
+        if (devices.empty()) devices.push_back((int)device);
+        rc = smafa_query_multi(database, query, max_div, max_hits, limit, 1, devices.data(), (int)devices.size());
     } else if (is_cluster) {
         if (!input) return usage("cluster needs --input");
         if (!have_max_div) {  // src/main.rs:43 unwraps the option

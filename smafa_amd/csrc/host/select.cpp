@@ -11,8 +11,10 @@
 namespace smafa {
 
 int select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint64_t n_subjects,
-                const uint8_t *subject_codes, uint32_t seq_len, uint32_t max_div, uint32_t max_num_hits,
-                uint32_t limit_per_sequence, std::vector<smafa_hit> &rows) {
+                const SubjectRows &subjects, uint32_t max_div, uint32_t max_num_hits, uint32_t limit_per_sequence,
+                std::vector<smafa_hit> &rows) {
+    const uint32_t seq_len = subjects.L;
+    std::vector<uint8_t> last_row, this_row;  // limit_per_sequence compares decoded subjects
     rows.clear();
     if (n_queries == 0) return SMAFA_OK;
     // src/lib.rs:224 — max_num_hits == 1 means the same as absent
@@ -26,8 +28,12 @@ int select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint
         return set_error(SMAFA_ERR_PANIC,
                          "limit_per_sequence is implemented unless max_num_hits > 1. It can be implemented by analogy, "
                          "just haven't gotten around to it.");
-    if (limit_per_sequence != SMAFA_NONE && !subject_codes)
+    if (limit_per_sequence != SMAFA_NONE && !subjects.codes && !subjects.packed)
         return set_error(SMAFA_ERR_INVALID, "limit_per_sequence needs the subject codes");
+    if (limit_per_sequence != SMAFA_NONE) {
+        last_row.resize(seq_len);
+        this_row.resize(seq_len);
+    }
     uint64_t i = 0;
     while (i < n_hits) {
         uint64_t j = i;
@@ -41,13 +47,13 @@ int select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint
             uint32_t kth = UINT32_MAX;
             if (!(max_num_hits > (uint32_t)n_subjects) && cnt >= max_num_hits) kth = hits[i + max_num_hits - 1].dist;
             bool have_last = false;
-            uint32_t last = 0, last_count = 0;
+            uint32_t last_count = 0;
             for (uint64_t t = i; t < j; t++) {
                 const smafa_hit &h = hits[t];
                 if (h.dist > kth || h.dist > max_div) break;  // ordered by distance: nothing further qualifies
                 if (limit_per_sequence != SMAFA_NONE) {       // :269-289, adjacent equal strings only
-                    const bool same = have_last && memcmp(subject_codes + (size_t)last * seq_len,
-                                                          subject_codes + (size_t)h.subject * seq_len, seq_len) == 0;
+                    subjects.get(h.subject, this_row.data());
+                    const bool same = have_last && memcmp(last_row.data(), this_row.data(), seq_len) == 0;
                     if (same) {
                         if (last_count >= limit_per_sequence) continue;
                         last_count++;
@@ -55,7 +61,7 @@ int select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint
                         last_count = 1;
                     }
                     have_last = true;
-                    last = h.subject;
+                    last_row.swap(this_row);
                 }
                 rows.push_back(h);
             }
@@ -78,8 +84,10 @@ extern "C" int smafa_select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_
                                  uint64_t *n_rows) {
     if (!n_rows || (!hits && n_hits) || (!rows && cap)) return smafa::set_error(SMAFA_ERR_INVALID, "smafa_select_rows: NULL argument");
     std::vector<smafa_hit> out;
-    const int rc = smafa::select_rows(hits, n_hits, n_queries, n_subjects, subject_codes, seq_len, max_div, max_num_hits,
-                                      limit_per_sequence, out);
+    smafa::SubjectRows subjects;
+    subjects.codes = subject_codes;
+    subjects.L = seq_len;
+    const int rc = smafa::select_rows(hits, n_hits, n_queries, n_subjects, subjects, max_div, max_num_hits, limit_per_sequence, out);
     if (rc) return rc;
     *n_rows = out.size();
     if (out.size() > cap)

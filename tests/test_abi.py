@@ -280,3 +280,18 @@ def test_dbfile_property_any_shape(tmp_path):
         assert open(c, "rb").read() == open(a, "rb").read()
 
     check()
+
+
+def test_query_multi_needs_devices_and_a_gpu(golden, tmp_path):
+    """smafa_query_multi: argument checks on any host; with no GPU the scan entry fails with SMAFA_ERR_DEVICE (no fallback)"""
+    import ctypes as C
+
+    l = _lib.lib()
+    db = os.fsencode(os.path.join(golden, "random_3_2.fna.smafadb"))
+    q = os.fsencode(os.path.join(golden, "random_3_2.fna"))
+    devs = (C.c_int * 2)(0, 0)
+    assert l.smafa_query_multi(db, q, _lib.NONE, _lib.NONE, _lib.NONE, 1, devs, 0) == _lib.ERR_INVALID
+    assert l.smafa_query_multi(db, q, _lib.NONE, _lib.NONE, _lib.NONE, 1, None, 2) == _lib.ERR_INVALID
+    if smafa_amd.device_count() == 0:
+        assert l.smafa_query_multi(db, q, _lib.NONE, _lib.NONE, _lib.NONE, 1, devs, 2) == _lib.ERR_DEVICE
+        assert b"no CPU fallback" in l.smafa_last_error()

@@ -188,3 +188,170 @@ def test_dense_rows_through_the_lds_stage_and_spill():
         want = oracle.scan_codes(s, q, D)
         assert len(got) == len(want) and got.tobytes() == want.tobytes(), D
     store.close()
+
+
+# ------------------------------------------------------------- one process, several handles (smafa_query_multi)
+def _write_fasta(path, ascii_rows):
+    with open(path, "wb") as f:
+        for i, r in enumerate(ascii_rows):
+            f.write(b">r%d\n" % i + bytes(r) + b"\n")
+
+
+@pytest.mark.parametrize("flags", [[], ["--max-divergence", "4"], ["--max-num-hits", "5"],
+                                   ["--max-num-hits", "4", "--limit-per-sequence", "1", "--max-divergence", "20"]])
+def test_query_multi_handles_equal_oracle_cli(tmp_path, flags):
+    """`smafa query --devices 0,0,..`: N handles on GPU 0, one host thread each, contiguous query blocks — stdout must be
+    byte-identical for N = 1, 2, 3 and equal to the oracle CLI's (src/lib.rs:232-318 carries no state across queries)."""
+    from smafa_amd import _lib
+
+    rng = np.random.default_rng(31)
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    s = letters[rng.integers(0, 4, size=(6000, 60))]
+    s[rng.random(size=s.shape) < 0.005] = ord("N")
+    s[100:140] = s[7]
+    q = s[rng.integers(0, len(s), size=211)].copy()
+    for r in q:
+        for _ in range(rng.integers(0, 7)):
+            r[rng.integers(0, 60)] = letters[rng.integers(0, 5)]
+    sf, qf, db = str(tmp_path / "s.fna"), str(tmp_path / "q.fna"), str(tmp_path / "db")
+    _write_fasta(sf, s)
+    _write_fasta(qf, q)
+    assert subprocess.run([_lib.CLI_PATH, "makedb", "-i", sf, "-d", db]).returncode == 0
+    want = oracle.run_cli("query", "-d", db, "-q", qf, *flags)
+    assert want.returncode == 0 and len(want.stdout) > 0
+    for devs in ("0", "0,0", "0,0,0"):
+        got = subprocess.run([_lib.CLI_PATH, "query", "-d", db, "-q", qf, "--devices", devs, *flags], capture_output=True, text=True)
+        assert got.returncode == 0, got.stderr
+        assert got.stdout == want.stdout, devs
+    got = subprocess.run([_lib.CLI_PATH, "query", "-d", db, "-q", qf, "--gpus", "1", *flags], capture_output=True, text=True)
+    assert got.returncode == 0 and got.stdout == want.stdout
+    # through the C ABI / Python mirror as well
+    out = str(tmp_path / "out.tsv")
+    fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    kw = {}
+    for i, f in enumerate(flags):
+        if f.startswith("--"):
+            kw[f[2:].replace("-", "_")] = int(flags[i + 1])
+    smafa_amd.query(db, qf, out_fd=fd, devices=[0, 0], **kw)
+    os.close(fd)
+    assert open(out).read() == want.stdout
+
+
+def test_query_multi_errors_and_partial_output(tmp_path):
+    from smafa_amd import _lib
+
+    sf, qf, db = str(tmp_path / "s.fna"), str(tmp_path / "q.fna"), str(tmp_path / "db")
+    open(sf, "wb").write(b">a\nACGTACGT\n>b\nTTTTACGT\n")
+    open(qf, "wb").write(b">q0\nACGTACGT\n>q1\nTTTTACGT\n>q2\nACGTAEGT\n>q3\nTTTTACGT\n")
+    assert subprocess.run([_lib.CLI_PATH, "makedb", "-i", sf, "-d", db]).returncode == 0
+    want = oracle.run_cli("query", "-d", db, "-q", qf)
+    got = subprocess.run([_lib.CLI_PATH, "query", "-d", db, "-q", qf, "--devices", "0,0"], capture_output=True, text=True)
+    assert got.returncode == want.returncode == 101
+    assert got.stdout == want.stdout == "0\t0\t0\tACGTACGT\n1\t1\t0\tTTTTACGT\n"
+    assert 'Byte 69 cannot be interpreted as nucleotide, in sequence "q2" at position 5' in got.stderr
+    bad = subprocess.run([_lib.CLI_PATH, "query", "-d", db, "-q", qf, "--devices", "0,99"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "device 99 out of range" in bad.stderr
+
+
+# ------------------------------------------------------------------ packed store file (makedb --packed)
+@pytest.mark.parametrize("with_n", [False, True])
+def test_packed_store_cli_round_trip(tmp_path, with_n):
+    """makedb --packed -> query: same bytes as the version-2 path and as the oracle CLI; the reference-side version gate
+    rejects the file with its own text; smafa_dbfile_read recovers the code rows from the bit-planes"""
+    from smafa_amd import _lib
+
+    rng = np.random.default_rng(71 + with_n)
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    s = letters[rng.integers(0, 4, size=(7000, 60))]
+    if with_n:
+        s[rng.random(size=s.shape) < 0.004] = ord("N")
+    s[50:90] = s[3]
+    q = s[rng.integers(0, len(s), size=160)].copy()
+    for r in q:
+        for _ in range(rng.integers(0, 7)):
+            r[rng.integers(0, 60)] = letters[rng.integers(0, 5)]
+    sf, qf = str(tmp_path / "s.fna"), str(tmp_path / "q.fna")
+    v2, pk = str(tmp_path / "v2.db"), str(tmp_path / "packed.db")
+    _write_fasta(sf, s)
+    _write_fasta(qf, q)
+    run = lambda *a: subprocess.run([_lib.CLI_PATH, *a], capture_output=True, text=True)
+    assert run("makedb", "-i", sf, "-d", v2).returncode == 0
+    r = run("makedb", "-i", sf, "-d", pk, "--packed")
+    assert r.returncode == 0, r.stderr
+    assert open(pk, "rb").read(8) == b"\x03\x02SMAFA\x00"
+    for flags in ([], ["--max-divergence", "5"], ["--max-num-hits", "4"], ["--max-num-hits", "5", "--limit-per-sequence", "1"]):
+        want = oracle.run_cli("query", "-d", v2, "-q", qf, *flags)
+        a, b = run("query", "-d", v2, "-q", qf, *flags), run("query", "-d", pk, "-q", qf, *flags)
+        assert a.returncode == b.returncode == want.returncode == 0, (a.stderr, b.stderr)
+        assert a.stdout == b.stdout == want.stdout and len(want.stdout) > 0, flags
+        c = run("query", "-d", pk, "-q", qf, "--devices", "0,0", *flags)
+        assert c.returncode == 0 and c.stdout == want.stdout
+    ref = oracle.run_cli("query", "-d", pk, "-q", qf)  # the reference's version gate, src/lib.rs:214-217
+    assert ref.returncode != 0 and "Unsupported db file version: 3." in ref.stderr
+    alphabet, codes = smafa_amd.read_db(pk)
+    _, codes2 = smafa_amd.read_db(v2)
+    assert alphabet == 0 and codes.tobytes() == codes2.tobytes()
+    info = smafa_amd.SubjectStore.load(pk).info()
+    assert info.planes == (3 if with_n else 2) and info.n_subjects == len(s)
+
+
+def test_packed_store_save_load_aa_and_appends(tmp_path):
+    rng = np.random.default_rng(12)
+    L = 60
+    parts = [rng.integers(0, 24, size=(m, L), dtype=np.uint8) for m in (9000, 100, 5000)]
+    s = np.concatenate(parts)
+    q = queries_from(rng, s, 130, 24, 7)
+    store = smafa_amd.SubjectStore(L, 1)
+    for p in parts:
+        store.push(p)
+    path = str(tmp_path / "aa.packed")
+    store.save(path)
+    want = oracle.scan_codes(s, q, 6)
+    assert store.scan(q, max_divergence=6).tobytes() == want.tobytes()
+    store.close()
+    back = smafa_amd.SubjectStore.load(path)
+    assert len(back) == len(s) and back.alphabet == 1 and back.seq_len == L
+    assert back.scan(q, max_divergence=6).tobytes() == want.tobytes()
+    assert back.scan(q, max_num_hits=1).tobytes() == expected_with_k(oracle.scan_codes(s, q, L), 1).tobytes()
+    extra = rng.integers(0, 24, size=(300, L), dtype=np.uint8)
+    back.push(extra)  # a loaded store is an ordinary store
+    s2 = np.concatenate([s, extra])
+    assert back.scan(q, max_divergence=6).tobytes() == oracle.scan_codes(s2, q, 6).tobytes()
+    assert (back.get_distances(q[0]) == oracle.distances_codes(s2, q[0])).all()
+    back.close()
+    alphabet, codes = smafa_amd.read_db(path)
+    assert alphabet == 1 and codes.tobytes() == s.tobytes()
+
+
+def test_packed_store_rejects_damaged_files(tmp_path):
+    rng = np.random.default_rng(2)
+    s = rng.integers(0, 4, size=(5000, 60), dtype=np.uint8)
+    store = smafa_amd.SubjectStore(60, 0)
+    store.push(s)
+    path = str(tmp_path / "ok.packed")
+    store.save(path)
+    store.close()
+    good = open(path, "rb").read()
+    import struct
+
+    def damaged(edit, name):
+        b = bytearray(good)
+        edit(b)
+        p = str(tmp_path / name)
+        open(p, "wb").write(bytes(b))
+        return p
+
+    cases = {
+        "trunc": lambda b: b.__delitem__(slice(len(b) - 4096, len(b))),
+        "rows": lambda b: b.__setitem__(slice(8 + 16, 8 + 24), struct.pack("<Q", 10**9)),     # n
+        "planes": lambda b: b.__setitem__(slice(8 + 8, 8 + 12), struct.pack("<I", 7)),        # planes
+        "perm": lambda b: b.__setitem__(slice(4096, 4098), struct.pack("<H", 60)),            # column 60 of 60
+        "tab": lambda b: b.__setitem__(slice(8192, 8194), b"\x00\x00"),                       # two codes -> one stored code
+        "offset": lambda b: b.__setitem__(slice(8 + 40 + 48, 8 + 40 + 56), struct.pack("<Q", len(good))),  # planes offset at the end
+    }
+    for name, edit in cases.items():
+        with pytest.raises(smafa_amd.SmafaError):
+            smafa_amd.SubjectStore.load(damaged(edit, name))
+        with pytest.raises(smafa_amd.SmafaError):
+            smafa_amd.read_db(damaged(edit, name))
+    smafa_amd.SubjectStore.load(damaged(lambda b: None, "same")).close()
