@@ -332,9 +332,15 @@ int smafa_query_multi(const char *db_path, const char *query_fasta, uint32_t max
     log_line(2, "db %s: %llu sequences of length %u in %.2f s", packed ? "mapped" : "decoded", (unsigned long long)n, L,
              now_seconds() - t_start);
 
+    // Query files of 32 MB and more (after decompression) are parsed and encoded up front by all threads
+    // (load_records_bulk: FASTA or FASTQ, plain or gzip); smaller ones are streamed record by record.
+    const uint64_t q_bytes = fastx_expanded_size(query_fasta);
+    const bool bulk_queries = n > 0 && q_bytes >= (32u << 20) && q_bytes <= (4ull << 30);
     FastxReader reader;
-    rc = reader.open(query_fasta);  // src/lib.rs:221
-    if (rc) return rc;
+    if (!bulk_queries) {
+        rc = reader.open(query_fasta);  // src/lib.rs:221
+        if (rc) return rc;
+    }
 
     std::vector<DbGuard> guards((size_t)ndev);
     // run fn(g) for every handle on its own host thread (HIP's current device is per thread); first failure in handle order
@@ -426,9 +432,9 @@ int smafa_query_multi(const char *db_path, const char *query_fasta, uint32_t max
         pending_msg = msg;
     };
 
-    if (n > 0 && !reader.is_fastq() && reader.size() >= (32u << 20) && reader.size() <= (4ull << 30)) {
-        // big plain-FASTA query files: every record parsed and encoded up front by several threads (the loader stops
-        // at the first offending record in file order, like the loop below), then scanned chunk by chunk
+    if (bulk_queries) {
+        // big query files: every record parsed and encoded up front by several threads (the loader stops at the
+        // first offending record in file order, like the loop below), then scanned chunk by chunk
         BulkRecords recs;
         rc = load_records_bulk(query_fasta, alphabet, false, recs);
         if (rc) return rc;

@@ -166,232 +166,473 @@ int FastxReader::next(FastxRecord &rec) {
 
 // ---------------------------------------------------------------------------------------------- bulk loading
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 namespace smafa {
 
 namespace {
 
-struct ChunkResult {
-    uint64_t n_records = 0;   // records that start in the chunk
-    uint64_t good = 0;        // parsed without error, in order
-    int err_kind = 0;
-    size_t err_len = 0;
-    std::string err_msg;
+// How much of the input is in memory: a mapped plain file is all there; a gzip file is inflated by one thread (a gzip
+// stream cannot be split) while the parser threads work on the part that has already come out.
+struct Progress {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t avail = 0;
+    bool done = false, failed = false;
+    void publish(size_t n, bool fin, bool fail = false) {
+        {
+            std::lock_guard<std::mutex> g(m);
+            avail = n;
+            done = done || fin;
+            failed = failed || fail;
+        }
+        cv.notify_all();
+    }
+    // blocks until `need` bytes are available or the stream has ended; returns the bytes available
+    size_t wait_for(size_t need) {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [&] { return avail >= need || done; });
+        return avail;
+    }
 };
 
-// parse the records starting in [lo, hi) of a FASTA buffer into rows first_row.. of codes/raw
-void parse_fasta_chunk(const uint8_t *d, size_t n, size_t lo, size_t hi, int alphabet, size_t L, uint64_t first_row,
-                       uint8_t *codes, uint8_t *raw, ChunkResult &res) {
+inline size_t line_end(const uint8_t *d, size_t limit, size_t from) {  // index of the '\n' ending the line, or limit
+    const void *q = from < limit ? memchr(d + from, '\n', limit - from) : nullptr;
+    return q ? (size_t)((const uint8_t *)q - d) : limit;
+}
+
+constexpr size_t kUndecided = (size_t)-1;
+
+// Start of the first record at or after `from`, looking at d[0 .. limit) of a `total`-byte input.
+//   FASTA: a '>' that begins a line — unambiguous.
+//   FASTQ (4-line records): an '@' that begins a line, whose third line begins with '+' and whose fourth line is as long
+//   as its second.  A quality line may begin with '@' too; then the "second line" is the next header and the "third" a
+//   sequence line, which cannot begin with '+' in valid input — and the loader checks every chunk against its
+//   neighbour afterwards, falling back to the one-thread reader if a boundary was wrong.
+// Returns total when there is no further record, kUndecided when the answer needs bytes past `limit`.
+size_t snap_record_start(const uint8_t *d, size_t limit, size_t total, size_t from, bool fastq) {
+    size_t p = from;
+    if (p > 0) {  // move to a line start
+        const size_t e = line_end(d, limit, p - 1);
+        if (e == limit) return limit < total ? kUndecided : total;
+        p = e + 1;
+    }
+    while (true) {
+        if (p >= limit) return limit < total ? kUndecided : total;
+        if (d[p] == (fastq ? '@' : '>')) {
+            if (!fastq) return p;
+            const size_t e1 = line_end(d, limit, p);
+            const size_t e2 = e1 < limit ? line_end(d, limit, e1 + 1) : limit;
+            const size_t e3 = e2 < limit ? line_end(d, limit, e2 + 1) : limit;
+            const size_t e4 = e3 < limit ? line_end(d, limit, e3 + 1) : limit;
+            if (e4 == limit && limit < total) return kUndecided;
+            if (e3 < limit && e2 + 1 < limit && d[e2 + 1] == '+') {
+                size_t sl = e2 - (e1 + 1), ql = e4 - (e3 + 1);
+                if (sl && d[e2 - 1] == '\r') sl--;
+                if (ql && e4 > e3 + 1 && d[e4 - 1] == '\r') ql--;
+                if (sl == ql) return p;
+            }
+        }
+        const size_t e = line_end(d, limit, p);
+        if (e == limit) return limit < total ? kUndecided : total;
+        p = e + 1;
+    }
+}
+
+struct ChunkOut {
+    std::vector<uint8_t> codes, raw;
+    uint64_t good = 0;    // records parsed without error, in order
+    size_t L = 0;         // length of the chunk's first record
+    bool have_L = false;
+    size_t lo = 0, hi = 0, end_pos = 0;  // [lo, hi): where the chunk's records start; end_pos: where its parse stopped
+    int err_kind = 0;     // as BulkRecords
+    size_t err_len = 0;
+    std::string err_msg;
+    bool truncated = false;  // a line ran into the end of the bytes available so far: parse again when more are there
+};
+
+void bad_byte(ChunkOut &c, int alphabet, uint8_t byte, const uint8_t *id, size_t id_len, size_t pos) {
+    char msg[512];
+    snprintf(msg, sizeof msg, "Byte %u cannot be interpreted as %s, in sequence \"%.*s\" at position %zu", byte,
+             alphabet_noun(alphabet), (int)std::min<size_t>(id_len, 300), (const char *)id, pos);
+    c.err_kind = 1;
+    c.err_msg = msg;
+}
+
+// parse the records starting in [c.lo, c.hi) of d[0..n) into c (FASTA, multi-line joined, or 4-line FASTQ); the whole
+// input has `total` bytes, of which n are in memory
+void parse_chunk(const uint8_t *d, size_t n, size_t total, bool fastq, int alphabet, bool want_raw, ChunkOut &c) {
     std::vector<uint8_t> seq;
-    size_t p = lo;
-    uint64_t row = first_row;
-    auto eol = [&](size_t from) {
-        const void *q = from < n ? memchr(d + from, '\n', n - from) : nullptr;
-        return q ? (size_t)((const uint8_t *)q - d) : n;
+    size_t p = c.lo;
+    auto line_end = [&](const uint8_t *dd, size_t lim, size_t from) {
+        const size_t e = smafa::line_end(dd, lim, from);
+        if (e == lim && lim < total) c.truncated = true;
+        return e;
     };
-    while (p < hi) {
-        // p is at a '>' that begins a line
-        const size_t hs = p + 1, he = eol(hs);
+    const char marker = fastq ? '@' : '>';
+    while (p < c.hi && (d[p] == '\n' || d[p] == '\r')) p++;
+    while (p < c.hi) {
+        if (d[p] != marker) {
+            c.err_kind = 4;
+            c.err_msg = fastq ? "record does not start with '@'" : "record does not start with '>'";
+            c.end_pos = p;
+            return;
+        }
+        const size_t hs = p + 1, he = line_end(d, n, hs);
         size_t id_len = he - hs;
         if (id_len && d[hs + id_len - 1] == '\r') id_len--;
         size_t q = he < n ? he + 1 : n;
         const uint8_t *s;
         size_t slen;
-        const size_t le0 = eol(q);
-        const size_t q2 = le0 < n ? le0 + 1 : n;
-        if ((q2 >= n || d[q2] == '>') && !(le0 > q && memchr(d + q, '\r', le0 - q))) {
-            s = d + q;  // one sequence line, no CR: in place
-            slen = le0 - q;
-            q = q2;
-        } else {
-            seq.clear();
-            while (q < n && d[q] != '>') {
-                const size_t le = eol(q);
-                for (size_t i = q; i < le; i++)
-                    if (d[i] != '\r') seq.push_back(d[i]);
-                q = le < n ? le + 1 : n;
-            }
-            s = seq.data();
-            slen = seq.size();
-        }
-        // encode first (src/lib.rs:150,235: from_bytes runs before any length check), into a scratch row if the
-        // length is wrong so that a bad byte in an over-long record is still reported
-        uint8_t *crow = codes + (size_t)row * L;
-        for (size_t i = 0; i < slen; i++) {
-            const uint8_t c = code_of(alphabet, s[i]);
-            if (c == 255) {
-                char msg[512];
-                snprintf(msg, sizeof msg, "Byte %u cannot be interpreted as %s, in sequence \"%.*s\" at position %zu", s[i],
-                         alphabet_noun(alphabet), (int)std::min<size_t>(id_len, 300), (const char *)(d + hs), i);
-                res.err_kind = 1;
-                res.err_msg = msg;
+        if (fastq) {
+            const size_t le = line_end(d, n, q);
+            slen = le - q;
+            if (slen && d[q + slen - 1] == '\r') slen--;
+            s = d + q;
+            q = le < n ? le + 1 : n;
+            if (q >= n || d[q] != '+') {
+                c.err_kind = 4;
+                c.err_msg = "FASTQ record without '+' line";
+                c.end_pos = p;
                 return;
             }
-            if (i < L) crow[i] = c;
+            const size_t pe = line_end(d, n, q);
+            q = pe < n ? pe + 1 : n;
+            const size_t qe = line_end(d, n, q);
+            size_t qlen = qe - q;
+            if (qlen && d[q + qlen - 1] == '\r') qlen--;
+            if (qlen != slen) {
+                c.err_kind = 4;
+                c.err_msg = "sequence and quality lengths differ";
+                c.end_pos = p;
+                return;
+            }
+            q = qe < n ? qe + 1 : n;
+        } else {
+            const size_t le0 = line_end(d, n, q);
+            const size_t q2 = le0 < n ? le0 + 1 : n;
+            if ((q2 >= n || d[q2] == '>') && !(le0 > q && memchr(d + q, '\r', le0 - q))) {
+                s = d + q;  // one sequence line, no CR: in place
+                slen = le0 - q;
+                q = q2;
+            } else {
+                seq.clear();
+                while (q < n && d[q] != '>') {
+                    const size_t le = line_end(d, n, q);
+                    for (size_t i = q; i < le; i++)
+                        if (d[i] != '\r') seq.push_back(d[i]);
+                    q = le < n ? le + 1 : n;
+                }
+                s = seq.data();
+                slen = seq.size();
+            }
         }
-        if (slen != L) {
-            res.err_kind = 2;
-            res.err_len = slen;
+        if (!c.have_L) {
+            c.L = slen;
+            c.have_L = true;
+        }
+        // encode first (src/lib.rs:150,235: from_bytes runs before any length check)
+        const size_t base = c.codes.size();
+        c.codes.resize(base + slen);
+        for (size_t i = 0; i < slen; i++) {
+            const uint8_t code = code_of(alphabet, s[i]);
+            if (code == 255) {
+                c.codes.resize(base);
+                bad_byte(c, alphabet, s[i], d + hs, id_len, i);
+                c.end_pos = p;
+                return;
+            }
+            c.codes[base + i] = code;
+        }
+        if (slen != c.L) {
+            c.codes.resize(base);
+            c.err_kind = 2;
+            c.err_len = slen;
+            c.end_pos = p;
             return;
         }
-        if (raw) memcpy(raw + (size_t)row * L, s, L);
-        row++;
-        res.good++;
+        if (want_raw) c.raw.insert(c.raw.end(), s, s + slen);
+        c.good++;
         p = q;
-        while (p < hi && (d[p] == '\n' || d[p] == '\r')) p++;  // blank lines between records
-        if (p < hi && d[p] != '>') {
-            res.err_kind = 4;
-            res.err_msg = "record does not start with '>'";
+        while (p < c.hi && (d[p] == '\n' || d[p] == '\r')) p++;
+    }
+    c.end_pos = p;
+}
+
+// one-thread loader over FastxReader: the definition of the loader's behaviour, and its fallback
+int load_sequential(FastxReader &reader, int alphabet, bool want_raw, BulkRecords &out) {
+    FastxRecord rec;
+    int rc;
+    while ((rc = reader.next(rec)) == 1) {
+        if (out.n == 0) out.L = rec.seq_len;
+        const size_t base = out.codes.size();
+        out.codes.resize(base + rec.seq_len);
+        for (size_t i = 0; i < rec.seq_len; i++) {
+            const uint8_t c = code_of(alphabet, rec.seq[i]);
+            if (c == 255) {
+                out.codes.resize(base);
+                char msg[512];
+                snprintf(msg, sizeof msg, "Byte %u cannot be interpreted as %s, in sequence \"%.*s\" at position %zu",
+                         rec.seq[i], alphabet_noun(alphabet), (int)std::min<size_t>(rec.id_len, 300), (const char *)rec.id, i);
+                out.err_kind = 1;
+                out.err_msg = msg;
+                return SMAFA_OK;
+            }
+            out.codes[base + i] = c;
+        }
+        if (out.n == 0 && rec.seq_len == 0) {
+            out.codes.resize(base);
+            out.err_kind = 3;
+            return SMAFA_OK;
+        }
+        if (rec.seq_len != out.L) {
+            out.codes.resize(base);
+            out.err_kind = 2;
+            out.err_len = rec.seq_len;
+            return SMAFA_OK;
+        }
+        if (want_raw) out.raw.insert(out.raw.end(), rec.seq, rec.seq + rec.seq_len);
+        out.n++;
+    }
+    if (rc < 0) {
+        out.err_kind = 4;
+        out.err_msg = smafa_last_error();
+    }
+    return SMAFA_OK;
+}
+
+// a mapped file
+struct Mapped {
+    const uint8_t *p = nullptr;
+    size_t len = 0;
+    ~Mapped() {
+        if (p) munmap((void *)p, len);
+    }
+    bool open(const char *path) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0;
+        if (ok) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            ok = m != MAP_FAILED;
+            if (ok) {
+                p = (const uint8_t *)m;
+                len = (size_t)st.st_size;
+            }
+        }
+        close(fd);
+        return ok;
+    }
+};
+
+// Threaded parse of d[0..total) — FASTA or 4-line FASTQ — as the bytes become available.  Returns false when the
+// chunking could not be trusted (a boundary was not a record start, the inflate failed, ...): the caller then runs
+// the one-thread reader, whose result is the definition.
+bool load_parallel(const uint8_t *d, size_t total, Progress &pr, bool fastq, int alphabet, bool want_raw, unsigned T,
+                   BulkRecords &out) {
+    std::vector<ChunkOut> chunks(T);
+    std::atomic<bool> distrust{false};
+    const size_t slack = 1u << 20;  // a boundary is looked for within this much beyond the raw cut (then: wait for the end)
+    auto boundary = [&](size_t raw_cut) -> size_t {
+        if (raw_cut == 0) return 0;
+        if (raw_cut >= total) return total;
+        size_t have = pr.wait_for(std::min(total, raw_cut + slack));
+        while (true) {
+            const size_t b = snap_record_start(d, std::min(have, total), total, raw_cut, fastq);
+            if (b != kUndecided) return b;
+            if (have >= total) return total;
+            const size_t more = pr.wait_for(std::min(total, have + slack));
+            if (more == have) return total;  // stream ended short: the inflate thread reports the failure
+            have = more;
+        }
+    };
+    auto work = [&](unsigned t) {
+        ChunkOut &c = chunks[t];
+        c.lo = boundary((size_t)((unsigned __int128)total * t / T));
+        c.hi = boundary((size_t)((unsigned __int128)total * (t + 1) / T));
+        // every record that STARTS before hi is parsed to its end: wait for the bytes after hi as well
+        const size_t need = std::min(total, c.hi + slack);
+        const size_t have = pr.wait_for(need);
+        if (have < need) {  // stream ended short of the announced size
+            distrust = true;
             return;
         }
+        c.codes.reserve((c.hi - c.lo) / 2);
+        parse_chunk(d, std::min(have, total), total, fastq, alphabet, want_raw, c);
+        if (c.truncated) {  // a record longer than the slack: once more with everything there
+            const size_t lo = c.lo, hi = c.hi;
+            c = ChunkOut();
+            c.lo = lo;
+            c.hi = hi;
+            if (pr.wait_for(total) < total) {
+                distrust = true;
+                return;
+            }
+            parse_chunk(d, total, total, fastq, alphabet, want_raw, c);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; t++) pool.emplace_back(work, t);
+    for (auto &th : pool) th.join();
+    {
+        std::lock_guard<std::mutex> g(pr.m);
+        if (pr.failed) return false;
     }
+    if (distrust) return false;
+    // chunks in file order: each must end where the next begins; the first error decides
+    unsigned last = T;  // chunks [0, last) contribute rows; chunk `last - 1` may carry the error
+    if (!chunks[0].have_L) return false;
+    for (unsigned t = 0; t < T; t++) {
+        ChunkOut &c = chunks[t];
+        if (c.err_kind == 4) return false;  // malformed record: the one-thread reader words the message
+        if (t > 0 && c.lo != chunks[t - 1].hi) return false;
+        if (t > 0 && c.have_L && chunks[0].have_L && c.L != chunks[0].L && c.good + (c.err_kind ? 1 : 0) > 0) {
+            // its FIRST record has another length than the file's first record: that record is the offender (a bad
+            // byte in it would have been reported first, src/lib.rs:235-238) — unless it already failed to encode
+            if (!(c.err_kind == 1 && c.good == 0)) {
+                c.err_kind = 2;
+                c.err_len = c.L;
+            }
+            c.good = 0;
+            c.codes.clear();
+            c.raw.clear();
+        }
+        if (c.err_kind) {
+            last = t + 1;
+            break;
+        }
+        if (c.end_pos != c.hi) return false;  // a record straddled the boundary: the snap was wrong
+    }
+    const ChunkOut &first = chunks[0];
+    out.L = first.have_L ? first.L : 0;
+    if (first.L == 0) {
+        out.err_kind = 3;  // the first record is empty (src/lib.rs:103-108)
+        return true;
+    }
+    uint64_t rows = 0;
+    std::vector<uint64_t> row0(last, 0);
+    for (unsigned t = 0; t < last; t++) {
+        row0[t] = rows;
+        rows += chunks[t].good;
+    }
+    const size_t L = out.L;
+    out.n = rows;
+    out.codes.resize((size_t)rows * L);
+    if (want_raw) out.raw.resize((size_t)rows * L);
+    {
+        std::vector<std::thread> copy;
+        for (unsigned t = 0; t < last; t++)
+            copy.emplace_back([&, t] {
+                const ChunkOut &c = chunks[t];
+                if (c.good == 0) return;
+                memcpy(out.codes.data() + (size_t)row0[t] * L, c.codes.data(), (size_t)c.good * L);
+                if (want_raw) memcpy(out.raw.data() + (size_t)row0[t] * L, c.raw.data(), (size_t)c.good * L);
+            });
+        for (auto &th : copy) th.join();
+    }
+    if (last > 0 && chunks[last - 1].err_kind) {
+        out.err_kind = chunks[last - 1].err_kind;
+        out.err_len = chunks[last - 1].err_len;
+        out.err_msg = chunks[last - 1].err_msg;
+    }
+    return true;
 }
 
 }  // namespace
 
+uint64_t fastx_expanded_size(const char *path) {
+    Mapped f;
+    if (!f.open(path)) return 0;
+    if (f.len >= 18 && f.p[0] == 0x1f && f.p[1] == 0x8b) {  // gzip: ISIZE, the last member's size mod 2^32
+        uint32_t isize;
+        memcpy(&isize, f.p + f.len - 4, 4);
+        return std::max<uint64_t>(isize, f.len);
+    }
+    return f.len;
+}
+
 int load_records_bulk(const char *path, int alphabet, bool want_raw, BulkRecords &out) {
     out = BulkRecords();
+    const unsigned n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    Mapped file;
+    const bool mapped = file.open(path);
+    const bool gz = mapped && file.len >= 18 && file.p[0] == 0x1f && file.p[1] == 0x8b;
+    if (mapped && n_threads >= 2 && !gz && file.len >= (32u << 20) && (file.p[0] == '>' || file.p[0] == '@')) {
+        // big plain file: every thread parses its share of the mapping
+        Progress pr;
+        pr.publish(file.len, true);
+        if (load_parallel(file.p, file.len, pr, file.p[0] == '@', alphabet, want_raw, n_threads, out)) {
+            log_line(2, "%s: %s, %llu records parsed by %u threads", path, file.p[0] == '@' ? "FASTQ" : "FASTA",
+                     (unsigned long long)out.n, n_threads);
+            return SMAFA_OK;
+        }
+        out = BulkRecords();
+    } else if (gz && n_threads >= 2) {
+        uint32_t isize;
+        memcpy(&isize, file.p + file.len - 4, 4);
+        if (isize >= (32u << 20) && (uint64_t)isize >= file.len / 2) {
+            // big single-member gzip file: one thread inflates into a buffer of the announced size, the others parse
+            // what has come out.  Anything unexpected (more members, another size) -> the one-thread reader below.
+            std::vector<uint8_t> buf((size_t)isize);
+            Progress pr;
+            std::thread inflater([&] {
+                z_stream zs;
+                memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, 15 + 16) != Z_OK) {
+                    pr.publish(0, true, true);
+                    return;
+                }
+                size_t in_pos = 0, out_done = 0;
+                bool ok = true, end = false;
+                while (ok && !end) {
+                    if (zs.avail_in == 0) {
+                        if (in_pos >= file.len) {
+                            ok = false;  // input exhausted before the stream ended
+                            break;
+                        }
+                        const size_t chunk = std::min<size_t>(file.len - in_pos, 1u << 30);
+                        zs.next_in = const_cast<Bytef *>(file.p + in_pos);
+                        zs.avail_in = (uInt)chunk;
+                        in_pos += chunk;
+                    }
+                    const size_t room = buf.size() - out_done;
+                    uint8_t probe;  // the announced size is used up: the stream must end without producing another byte
+                    zs.next_out = room ? buf.data() + out_done : &probe;
+                    zs.avail_out = room ? (uInt)std::min<size_t>(room, 4u << 20) : 1u;
+                    const int r = inflate(&zs, Z_NO_FLUSH);
+                    if (room) out_done = (size_t)(zs.next_out - buf.data());
+                    else if (zs.avail_out == 0) ok = false;  // more output than announced
+                    if (r == Z_STREAM_END) end = true;
+                    else if (r != Z_OK && r != Z_BUF_ERROR) ok = false;
+                    if (ok) pr.publish(out_done, false);
+                }
+                const bool whole = ok && end && out_done == buf.size() && in_pos - zs.avail_in == file.len;
+                inflateEnd(&zs);
+                pr.publish(out_done, true, !whole);
+            });
+            // format by first byte, once the first block is out
+            const size_t have = pr.wait_for(1);
+            bool ok = have >= 1 && (buf[0] == '>' || buf[0] == '@');
+            if (ok) ok = load_parallel(buf.data(), buf.size(), pr, buf[0] == '@', alphabet, want_raw, n_threads - 1, out);
+            inflater.join();
+            if (ok) {
+                log_line(2, "%s: gzip %s, %llu records parsed by %u threads while one thread inflated", path,
+                         buf[0] == '@' ? "FASTQ" : "FASTA", (unsigned long long)out.n, n_threads - 1);
+                return SMAFA_OK;
+            }
+            out = BulkRecords();
+        }
+    }
     FastxReader reader;
     int rc = reader.open(path);
     if (rc) return rc;
-    const uint8_t *d = reader.data();
-    const size_t n = reader.size();
-    unsigned n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (reader.is_fastq() || n < (32u << 20) || n_threads < 2) {
-        // sequential path: FastxReader record by record
-        FastxRecord rec;
-        while ((rc = reader.next(rec)) == 1) {
-            if (out.n == 0) {
-                out.L = rec.seq_len;
-            }
-            const size_t base = out.codes.size();
-            out.codes.resize(base + rec.seq_len);
-            for (size_t i = 0; i < rec.seq_len; i++) {
-                const uint8_t c = code_of(alphabet, rec.seq[i]);
-                if (c == 255) {
-                    out.codes.resize(base);
-                    char msg[512];
-                    snprintf(msg, sizeof msg, "Byte %u cannot be interpreted as %s, in sequence \"%.*s\" at position %zu",
-                             rec.seq[i], alphabet_noun(alphabet), (int)std::min<size_t>(rec.id_len, 300), (const char *)rec.id, i);
-                    out.err_kind = 1;
-                    out.err_msg = msg;
-                    return SMAFA_OK;
-                }
-                out.codes[base + i] = c;
-            }
-            if (out.n == 0 && rec.seq_len == 0) {
-                out.codes.resize(base);
-                out.err_kind = 3;
-                return SMAFA_OK;
-            }
-            if (rec.seq_len != out.L) {
-                out.codes.resize(base);
-                out.err_kind = 2;
-                out.err_len = rec.seq_len;
-                return SMAFA_OK;
-            }
-            if (want_raw) out.raw.insert(out.raw.end(), rec.seq, rec.seq + rec.seq_len);
-            out.n++;
-        }
-        if (rc < 0) {
-            out.err_kind = 4;
-            out.err_msg = smafa_last_error();
-        }
-        return SMAFA_OK;
-    }
-    // parallel path (plain FASTA): the first record fixes L
-    {
-        FastxRecord rec;
-        rc = reader.next(rec);
-        if (rc < 0) {
-            out.err_kind = 4;
-            out.err_msg = smafa_last_error();
-            return SMAFA_OK;
-        }
-        if (rc == 0) return SMAFA_OK;
-        out.L = rec.seq_len;
-        if (rec.seq_len == 0) {
-            // still report a bad byte first?  an empty sequence has none
-            out.err_kind = 3;
-            return SMAFA_OK;
-        }
-    }
-    const size_t L = out.L;
-    // chunk boundaries snapped forward to the next record start ('>' after '\n')
-    std::vector<size_t> bounds(n_threads + 1, n);
-    bounds[0] = 0;
-    for (unsigned t = 1; t < n_threads; t++) {
-        size_t p = (size_t)((unsigned __int128)n * t / n_threads);
-        while (true) {
-            const void *q = p < n ? memchr(d + p, '>', n - p) : nullptr;
-            if (!q) {
-                p = n;
-                break;
-            }
-            p = (size_t)((const uint8_t *)q - d);
-            if (p == 0 || d[p - 1] == '\n') break;
-            p++;
-        }
-        bounds[t] = p;
-    }
-    for (unsigned t = 1; t <= n_threads; t++) bounds[t] = std::max(bounds[t], bounds[t - 1]);
-    // pass 1: count record starts per chunk
-    std::vector<ChunkResult> res(n_threads);
-    {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < n_threads; t++)
-            pool.emplace_back([&, t] {
-                uint64_t c = 0;
-                size_t p = bounds[t];
-                const size_t hi = bounds[t + 1];
-                while (p < hi) {
-                    const void *q = memchr(d + p, '>', hi - p);
-                    if (!q) break;
-                    p = (size_t)((const uint8_t *)q - d);
-                    if (p == 0 || d[p - 1] == '\n') c++;
-                    p++;
-                }
-                res[t].n_records = c;
-            });
-        for (auto &th : pool) th.join();
-    }
-    uint64_t total = 0;
-    std::vector<uint64_t> first_row(n_threads);
-    for (unsigned t = 0; t < n_threads; t++) {
-        first_row[t] = total;
-        total += res[t].n_records;
-    }
-    out.codes.resize((size_t)total * L);
-    if (want_raw) out.raw.resize((size_t)total * L);
-    // pass 2: parse + encode
-    {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < n_threads; t++)
-            pool.emplace_back([&, t] {
-                size_t lo = bounds[t];
-                while (lo < bounds[t + 1] && (d[lo] == '\n' || d[lo] == '\r')) lo++;
-                if (lo < bounds[t + 1])
-                    parse_fasta_chunk(d, n, lo, bounds[t + 1], alphabet, L, first_row[t], out.codes.data(),
-                                      want_raw ? out.raw.data() : nullptr, res[t]);
-            });
-        for (auto &th : pool) th.join();
-    }
-    // first error in file order decides
-    uint64_t good = 0;
-    for (unsigned t = 0; t < n_threads; t++) {
-        good += res[t].good;
-        if (res[t].err_kind) {
-            out.err_kind = res[t].err_kind;
-            out.err_len = res[t].err_len;
-            out.err_msg = res[t].err_msg;
-            break;
-        }
-    }
-    out.n = good;
-    out.codes.resize((size_t)good * L);
-    if (want_raw) out.raw.resize((size_t)good * L);
-    return SMAFA_OK;
+    rc = load_sequential(reader, alphabet, want_raw, out);
+    log_line(2, "%s: %llu records through the one-thread reader", path, (unsigned long long)out.n);
+    return rc;
 }
 
 }  // namespace smafa

@@ -49,8 +49,11 @@ class FastxReader {
 namespace smafa {
 
 // Bulk load of a FASTA/FASTQ(+gzip) file of equal-length records into code rows (and optionally the raw sequence
-// bytes, for cluster's first output column).  Large plain-FASTA inputs are parsed by several threads — a record
-// starts at every '>' that begins a line, so the split is unambiguous — everything else goes through FastxReader.
+// bytes, for cluster's first output column).  Inputs of 32 MB and more are parsed and encoded by several threads: the
+// file is cut at record starts (FASTA: a '>' that begins a line; 4-line FASTQ: an '@' line whose third line is a '+'
+// line and whose fourth is as long as its second, verified against the neighbouring chunk afterwards); a gzip file is
+// inflated by one thread (a gzip stream cannot be split) while the others parse what has already come out.  Small
+// inputs, multi-member gzip files and anything the chunking cannot vouch for go through FastxReader on one thread.
 // Stops at the FIRST offending record in file order, exactly where the sequential reader would:
 //   err_kind 0 none | 1 byte outside the alphabet (err_msg = the reference's panic text) | 2 length differs from
 //   the first record's (err_len = its length) | 3 the first record is empty | 4 parse error (err_msg)
@@ -64,5 +67,8 @@ struct BulkRecords {
     std::string err_msg;
 };
 int load_records_bulk(const char *path, int alphabet, bool want_raw, BulkRecords &out);
+// Size of the file's contents once decompressed (gzip: the ISIZE trailer; plain: the file size; 0: cannot tell) — how the
+// drivers decide between streaming a query file and bulk-loading it with all threads.
+uint64_t fastx_expanded_size(const char *path);
 
 }  // namespace smafa

@@ -4,6 +4,7 @@ reference's golden vectors, and GPU entry points fail loudly without a device.  
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -295,3 +296,59 @@ def test_query_multi_needs_devices_and_a_gpu(golden, tmp_path):
     if smafa_amd.device_count() == 0:
         assert l.smafa_query_multi(db, q, _lib.NONE, _lib.NONE, _lib.NONE, 1, devs, 2) == _lib.ERR_DEVICE
         assert b"no CPU fallback" in l.smafa_last_error()
+
+
+def test_parallel_fastq_and_gzip_ingest_match_oracle(tmp_path):
+    """>= 32 MB of FASTQ, FASTA.gz and FASTQ.gz take the threaded loader (gzip: one inflating thread feeding the parsers);
+    rows equal the generator's, quality lines that begin with '@' do not confuse the chunking, and a damaged record
+    fails at the same record with the same text as the oracle's one-thread reader; multi-member gzip falls back."""
+    import gzip
+
+    from smafa_amd import synth
+    n, L = 620_000, 60
+    codes = synth.subjects(n, L, 0, seed=13, n_frac=0.01)
+    asc = np.frombuffer(b"ACGTN", dtype=np.uint8)[codes]
+
+    def fastq_bytes(patch=None):
+        parts = []
+        for i in range(n):
+            seq = patch[i] if patch and i in patch else asc[i].tobytes()
+            qual = (b"@" if i % 5 == 0 else b"I") * len(seq)
+            parts.append(b"@r%d\n" % i + seq + b"\n+\n" + qual + b"\n")
+        return b"".join(parts)
+
+    def load_log(path):  # which loader ran: the drivers' debug line on stderr
+        r = subprocess.run([sys.executable, "-c",
+                            "import sys; sys.path.insert(0, %r); import smafa_amd; from smafa_amd import _lib; "
+                            "_lib.lib().smafa_set_verbosity(2); a = smafa_amd.load_fastx(%r, 0); print(a.shape[0])" % (ROOT, path)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return r.stderr
+
+    body = fastq_bytes()
+    assert len(body) >= 64 << 20
+    fq, fqgz, fagz, multi = (str(tmp_path / x) for x in ("a.fq", "a.fq.gz", "a.fna.gz", "multi.fq.gz"))
+    open(fq, "wb").write(body)
+    with gzip.open(fqgz, "wb", compresslevel=1) as f:
+        f.write(body)
+    fa = b"".join(b">r%d\n" % i + asc[i].tobytes() + b"\n" for i in range(n))
+    with gzip.open(fagz, "wb", compresslevel=1) as f:
+        f.write(fa)
+    with open(multi, "wb") as f:  # two gzip members: the size trailer describes only the last one
+        half = body[: body.index(b"@r300000\n")]
+        f.write(gzip.compress(half, 1) + gzip.compress(body[len(half):], 1))
+    for path, expect in ((fq, "parsed by"), (fqgz, "while one thread inflated"), (fagz, "while one thread inflated"),
+                         (multi, "one-thread reader")):
+        assert (smafa_amd.load_fastx(path, 0) == codes).all(), path
+        assert expect in load_log(path), path
+    # damaged records: a byte outside the alphabet deep in the file, then (earlier in the file) a short record
+    for patch in ({500_123: asc[500_123].tobytes()[:17] + b"!" + asc[500_123].tobytes()[18:]},
+                  {500_123: asc[500_123].tobytes()[:17] + b"!" + asc[500_123].tobytes()[18:], 222_222: asc[222_222].tobytes()[:59]}):
+        bad = fastq_bytes(patch)
+        for path, writer in ((str(tmp_path / "bad.fq"), lambda p: open(p, "wb").write(bad)),
+                             (str(tmp_path / "bad.fq.gz"), lambda p: open(p, "wb").write(gzip.compress(bad, 1)))):
+            writer(path)
+            r = cli("makedb", "-i", path, "-d", str(tmp_path / "x.db"))
+            o = oracle.run_cli("makedb", "-i", path, "-d", str(tmp_path / "y.db"))
+            assert r.returncode == o.returncode == 101, path
+            assert r.stderr.strip().splitlines()[-1] == o.stderr.strip().splitlines()[-1], path

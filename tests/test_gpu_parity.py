@@ -689,3 +689,49 @@ def test_big_query_file_takes_the_threaded_loader_and_matches_oracle(tmp_path):
         assert got.returncode == want.returncode == 101, patch.keys()
         assert got.stdout == want.stdout
         assert got.stderr.strip().splitlines()[-1] == want.stderr.strip().splitlines()[-1]
+
+
+def test_big_fastq_and_gzip_query_files_take_the_threaded_loader(tmp_path):
+    """>= 32 MB .fq and .fq.gz query files: parsed by several threads (gzip: one inflating thread feeding them), the same
+    rows as the oracle CLI, and the same failure at the same record after the same rows"""
+    import gzip
+
+    rng = np.random.default_rng(123)
+    L, n, nq = 60, 300, 330_000  # 330k x (60 + 60 + header + 3) bytes = 44 MB of FASTQ
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    s = letters[rng.integers(0, 4, size=(n, L))]
+    q = s[rng.integers(0, n, size=nq)].copy()
+    sub = rng.random(size=q.shape) < 0.03
+    q[sub] = letters[rng.integers(0, 4, size=int(sub.sum()))]
+    sf, db = str(tmp_path / "s.fna"), str(tmp_path / "db")
+    oracle.write_fasta(sf, [bytes(r) for r in s])
+    assert cli("makedb", "-i", sf, "-d", db).returncode == 0
+
+    def body(patch=None):
+        out = bytearray()
+        for i, r in enumerate(q):
+            seq = patch[i] if patch and i in patch else bytes(r)
+            out += b"@q%d\n" % i + seq + b"\n+\n" + (b"@" if i % 3 == 0 else b"F") * len(seq) + b"\n"
+        assert len(out) >= 32 << 20
+        return bytes(out)
+
+    fq, gz = str(tmp_path / "q.fq"), str(tmp_path / "q.fq.gz")
+    good = body()
+    open(fq, "wb").write(good)
+    open(gz, "wb").write(gzip.compress(good, 1))
+    want = oracle.run_cli("query", "-d", db, "-q", fq, "--max-divergence", "2")
+    assert want.returncode == 0 and len(want.stdout) > 1_000_000
+    for path, note in ((fq, "parsed by"), (gz, "while one thread inflated")):
+        got = cli("query", "-d", db, "-q", path, "--max-divergence", "2", "-v")
+        assert got.returncode == 0, got.stderr[-2000:]
+        assert got.stdout == want.stdout, path
+        assert note in got.stderr, got.stderr[-2000:]
+    bad = body({250_001: bytes(q[250_001][:20]) + b"E" + bytes(q[250_001][21:]), 123_456: bytes(q[123_456][:58])})
+    open(fq, "wb").write(bad)
+    open(gz, "wb").write(gzip.compress(bad, 1))
+    want = oracle.run_cli("query", "-d", db, "-q", fq, "--max-divergence", "1")
+    for path in (fq, gz):
+        got = cli("query", "-d", db, "-q", path, "--max-divergence", "1")
+        assert got.returncode == want.returncode == 101, path
+        assert got.stdout == want.stdout
+        assert got.stderr.strip().splitlines()[-1] == want.stderr.strip().splitlines()[-1]
