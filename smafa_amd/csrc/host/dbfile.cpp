@@ -429,10 +429,18 @@ int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t
     } else {
         decode(0);
     }
+    // STRICTER than the reference, on purpose ("DB files"): a window group that is not one of the five
+    // one-hot codes — or an empty group before column L — fails the load.  The reference would keep such words, count
+    // their bits in every distance (src/lib.rs:80-88) and panic only when that subject is printed (src/lib.rs:127);
+    // makedb never writes them, so this only concerns damaged or hand-made files, and the text says so.
     for (int b : bad_symbol)
         if (b >= 0) {
             free(wide);
-            return set_error(SMAFA_ERR_PANIC, "Invalid character in query sequence: %u", (unsigned)b);
+            return set_error(SMAFA_ERR_FORMAT,
+                             "%s: a window holds the 5-bit group %u, which is not a one-hot nucleotide code (A=16 C=8 G=4 "
+                             "T=2 N=1): damaged store file (this build rejects it at load time; the reference would "
+                             "panic \"Invalid character in query sequence\" on printing that subject)",
+                             path, (unsigned)b);
         }
     uint8_t *out = wide;
     if (stride != L)  // compact in place (L < stride, ascending rows)

@@ -36,6 +36,12 @@ def shard_bounds(n_queries: int, world: int, rank: int) -> tuple[int, int]:
     return (rank * n_queries) // world, ((rank + 1) * n_queries) // world
 
 
+def _lib_err_other_rank() -> int:
+    from . import _lib
+
+    return _lib.ERR_DEVICE
+
+
 class HipScanner:
     """The product scanner: the subject store is packed into HBM on `device` at first use and every call
     runs the HIP scan kernels through the C ABI."""
@@ -144,17 +150,36 @@ def query_sharded(db_path: str, query_fasta: str, max_divergence: Optional[int] 
                              % (queries.shape[1], L))
     if scan_fn is None:
         scan_fn = HipScanner(alphabet, int(os.environ.get("LOCAL_RANK", rank)) if gpu is None else gpu)
+    # The reference's input-independent panics (empty store, k = 0, --limit-per-sequence without k > 1;
+    # src/lib.rs:254-255,298,301-303) are raised HERE, on every rank alike and before anything is sharded: a rank whose
+    # shard is empty would otherwise sail past them into the gather while the others have already left the group.
+    needs_panic = n == 0 or max_num_hits == 0 or (limit_per_sequence is not None and max_num_hits in (None, 1))
+    if len(queries) and needs_panic:  # raises the reference's panic, identically on every rank
+        api.select_rows(np.zeros(0, dtype=api.HIT_DTYPE), 1, n, subj, L, max_divergence, max_num_hits, limit_per_sequence)
     lo, hi = shard_bounds(len(queries), world, rank)
     kmode = max_num_hits is not None and max_num_hits != 1
     dev_k = 1 if not kmode else (None if (max_num_hits == 0 or max_num_hits > n) else max_num_hits)
     mine = queries[lo:hi]
-    if n and len(mine):
-        hits = scan_fn(subj, mine, max_divergence, dev_k)
-    else:
-        hits = np.zeros(0, dtype=api.HIT_DTYPE)
-    rows = api.select_rows(hits, len(mine), n, subj, L, max_divergence, max_num_hits, limit_per_sequence)
-    rows = rows.copy()
-    rows["query"] += lo  # global query numbers
+    failure = None
+    try:
+        if n and len(mine):
+            hits = scan_fn(subj, mine, max_divergence, dev_k)
+        else:
+            hits = np.zeros(0, dtype=api.HIT_DTYPE)
+        rows = api.select_rows(hits, len(mine), n, subj, L, max_divergence, max_num_hits, limit_per_sequence)
+        rows = rows.copy()
+        rows["query"] += lo  # global query numbers
+    except api.SmafaError as e:  # a failure only this rank sees (device trouble ...): tell the others before the gather
+        failure = e
+        rows = np.zeros(0, dtype=api.HIT_DTYPE)
+    import torch
+
+    flag = torch.tensor([1 if failure else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if failure:
+        raise failure
+    if int(flag.item()):
+        raise api.SmafaError(_lib_err_other_rank(), "another rank failed; no rows written")
     all_rows = gather_rows(rows, dist, device)
     if rank == 0:
         api.write_rows(all_rows, subj, alphabet, out_fd)

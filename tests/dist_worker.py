@@ -79,6 +79,9 @@ def main():
     try:
         sdist.query_sharded(a.db, a.queries, a.max_divergence, a.max_num_hits, a.limit_per_sequence,
                             out_fd=fd if fd >= 0 else 1, scan_fn=scan_fn, dist=dist)
+    except smafa_amd.SmafaPanic as e:  # the reference's panic: message on stderr, exit 101 (like the CLI)
+        sys.stderr.write(str(e) + "\n")
+        sys.exit(101)
     finally:
         if fd >= 0:
             os.close(fd)

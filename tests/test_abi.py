@@ -352,3 +352,25 @@ def test_parallel_fastq_and_gzip_ingest_match_oracle(tmp_path):
             o = oracle.run_cli("makedb", "-i", path, "-d", str(tmp_path / "y.db"))
             assert r.returncode == o.returncode == 101, path
             assert r.stderr.strip().splitlines()[-1] == o.stderr.strip().splitlines()[-1], path
+
+
+def test_db_with_a_non_one_hot_group_is_rejected_at_load(golden, tmp_path):
+    """deliberate restriction: the v2 loader refuses windows the reference's makedb cannot produce,
+    with its own text (not the reference's print-time panic) — pinned on a mutated copy of the reference's fixture"""
+    good = open(os.path.join(golden, "random_3_2.fna.smafadb"), "rb").read()
+    assert good == bytes.fromhex("020201c810019021" "0103")
+    # window 0 = varint(2120) = C | T<<5 | T<<10; make its first group 3 (two bits set): 2115 = c3 10
+    bad = good.replace(bytes.fromhex("c810"), bytes.fromhex("c310"), 1)
+    p = str(tmp_path / "bad.smafadb")
+    open(p, "wb").write(bad)
+    with pytest.raises(smafa_amd.SmafaError) as e:
+        smafa_amd.read_db(p)
+    assert e.value.code == _lib.ERR_FORMAT and "not a one-hot nucleotide code" in str(e.value)
+    assert not isinstance(e.value, smafa_amd.SmafaPanic)
+    r = cli("query", "-d", p, "-q", os.path.join(golden, "random_3_2.fna"))
+    assert r.returncode == 1 and r.stdout == "" and "damaged store file" in r.stderr
+    # an empty group inside the sequence (column 1 of window 0): 8 | 0<<5 | 2<<10 = 2056 = 88 10
+    empty = good.replace(bytes.fromhex("c810"), bytes.fromhex("8810"), 1)
+    open(p, "wb").write(empty)
+    with pytest.raises(smafa_amd.SmafaError):
+        smafa_amd.read_db(p)

@@ -76,6 +76,17 @@ def test_sharded_query_world2_gloo_equals_oracle(tmp_path, flags):
     assert len(want.stdout) > 0
 
 
+def test_sharded_query_panics_on_every_rank_without_hanging(tmp_path):
+    """fewer queries than ranks + an input the reference panics on (--limit-per-sequence without --max-num-hits > 1,
+    src/lib.rs:301-303): the rank with the empty shard must fail like the others instead of waiting in the gather"""
+    db, qf = make_inputs(tmp_path, q=1)
+    out = str(tmp_path / "out.tsv")
+    r = run_world(2, db, qf, out, ["--limit-per-sequence", "1"])
+    assert r.returncode != 0
+    assert r.stderr.count("limit_per_sequence is implemented unless max_num_hits > 1") >= 2, r.stderr[-3000:]
+    assert "Timeout" not in r.stderr and "timed out" not in r.stderr
+
+
 @pytest.mark.gpu
 def test_sharded_query_hip_scanner_equals_oracle(tmp_path):
     """same driver, product (HIP) scanner, 2 ranks sharing GPU 0 (gloo for the row gather)"""
