@@ -482,7 +482,7 @@ def main() -> int:
         k_s = kernel_ms_avg * 1e-3
         # VALU instructions and HBM traffic per launch: from the committed counter profile of this command, if it was
         # taken on this workload and kernel (rocprofv3 cannot run inside the timed process)
-        pmc, pmc_note = None, "no counter profile for this workload: instruction count from the kernel's instruction model"
+        pmc, pmc_note = None, "no counter profile of this workload and kernel in profiles/r02_pmc.json: achieved / frac not claimed"
         if os.path.exists(PMC_JSON):
             rec_all = json.load(open(PMC_JSON))
             for rec_ in rec_all.get("records", []):
@@ -495,16 +495,10 @@ def main() -> int:
                             "per launch of %s; recorded from build %s, this run is build %s"
                             % (kernel_name, pmc.get("build_id"), smafa_amd.build_id()))
         filt = os.environ.get("SMAFA_FILTER", "1") != "0"
-        if pmc:
-            valu_insts = float(pmc["per_launch"]["SQ_INSTS_VALU"])
-        else:
-            W_, P_ = info.words_per_plane, info.planes
-            ops_per_pair = (W_ + 1.75) if filt else (P_ * W_ + W_ + 1.0)
-            if filt and plan["filter_plane_resident"]:
-                T_ = plan["tiles_per_wave"]
-                ops_per_pair = (10.0 * T_ + 2.0) / (4.0 * T_)
-            valu_insts = pairs_per_launch * ops_per_pair / 64.0
-        lane_ops = valu_insts * 64.0 / k_s
+        # no counter profile for this workload/kernel: no instruction count is claimed (run tools/collect_pmc.py with the
+        # same flags and add its record to profiles/r02_pmc.json)
+        valu_insts = float(pmc["per_launch"]["SQ_INSTS_VALU"]) if pmc else None
+        lane_ops = valu_insts * 64.0 / k_s if valu_insts else None
         traffic = float(pmc["per_launch"]["hbm_bytes"]) if pmc and "hbm_bytes" in pmc["per_launch"] else None
         out = {
             "metric": "query seqs/sec (DB residues/sec in `residues_per_s`) vs roofline, %dM x %d%s DB, d<=%d"
@@ -543,10 +537,11 @@ def main() -> int:
             "roofline": {
                 "bound": "valu",
                 "kernel": kernel_name,
-                "achieved": lane_ops / 1e12,
+                "achieved": lane_ops / 1e12 if lane_ops else None,
                 "peak": VALU_PEAK_LANE_OPS / 1e12,
                 "unit": "Tlane-op/s",
-                "frac": lane_ops / VALU_PEAK_LANE_OPS,
+                "frac": lane_ops / VALU_PEAK_LANE_OPS if lane_ops else None,
+                "valu_insts_per_1024_pairs": valu_insts / (pairs_per_launch / 1024.0) if valu_insts else None,
                 "kernel_ms_avg": kernel_ms_avg,
                 "valu_insts_per_launch": valu_insts,
                 "insts_source": pmc_note,
@@ -562,8 +557,11 @@ def main() -> int:
                 "stored_bytes_per_subject": int(info.bytes_per_subject),
                 "note": "integer compare/reduce: the launch is bound by VALU issue, not HBM. peak = 256 CU x 4 SIMD x "
                         "32 lanes x 2.4 GHz (one wave64 op per 2 cycles); measured issue rates on this chip "
-                        "(profiles/r01_ubench_valu*.txt): all-VGPR xor/bitop3/add ~60e12, v_bcnt/v_cmp and any op with "
-                        "an SGPR source ~37e12 lane-ops/s. algorithmic_reuse_x = queries x subjects x %g B (SURVEY 8d) "
+                        "(profiles/r01_ubench_valu*.txt): all-VGPR xor/bitop3/add ~60e12, v_bcnt/v_cmp/v_readlane and any "
+                        "op with an SGPR source ~37e12 lane-ops/s = 0.48 of peak, and the zone kernel's survivor loop is "
+                        "made of those (frac / 0.48 = its share of the ceiling of its own instruction mix). The round-1 "
+                        "kernel ran 45 VALU instructions per 1024 pairs at frac 0.58; the zone level cuts the "
+                        "instructions per pair, not the cost of an instruction. algorithmic_reuse_x = queries x subjects x %g B (SURVEY 8d) "
                         "over kernel time over 8 TB/s: how many times the naive one-query-per-pass traffic would "
                         "exceed HBM peak — register reuse of a tile across a query block plus exact early-outs, NOT "
                         "an HBM efficiency; the HBM-bound form is in `stream`." % (L * sym_bits / 8),

@@ -142,7 +142,9 @@ static int choose_layout(smafa_db *db, const uint8_t *codes, uint64_t n) {
     const bool aa = db->alphabet == SMAFA_ALPHABET_AA;
     const uint32_t n_sym = aa ? 28u : 4u, side_cap = aa ? 16u : 2u;
     std::vector<uint32_t> cnt((size_t)L * 32, 0);
-    const uint64_t S = std::min<uint64_t>(n, 4096);
+    // SMAFA_LAYOUT=0 (A/B runs, tools/layout_check.py): no statistics — columns in file order, the default code split
+    const char *lv = getenv("SMAFA_LAYOUT");
+    const uint64_t S = (lv && atoi(lv) == 0) ? 0 : std::min<uint64_t>(n, 4096);
     for (uint64_t k = 0; k < S; k++) {
         const uint8_t *row = codes + (size_t)(k * n / S) * L;
         for (uint32_t c = 0; c < L; c++) cnt[(size_t)c * 32 + (row[c] & 31u)]++;
@@ -384,8 +386,12 @@ static void launch_zone_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
         hipLaunchKernelGGL((scan_zone_few_kernel<PS, PQ, W>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
         return;
     }
-    note_kernel(db, "smafa::scan_zone_kernel<%d, %d, %d>", PS, PQ, W);
-    hipLaunchKernelGGL((scan_zone_kernel<PS, PQ, W>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
+    const bool fixed = a.thr == nullptr;  // one bound for every query: LDS-DMA staging, scalar bound
+    note_kernel(db, "smafa::scan_zone_kernel<%d, %d, %d, %s>", PS, PQ, W, fixed ? "true" : "false");
+    if (fixed)
+        hipLaunchKernelGGL((scan_zone_kernel<PS, PQ, W, true>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
+    else
+        hipLaunchKernelGGL((scan_zone_kernel<PS, PQ, W, false>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
 }
 
 template <int PS, int PQ, int W, int T>

@@ -750,10 +750,23 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
 // Where the prefilter stops paying for a wave (dense neighbourhoods) it falls back to the plain comparison with one
 // tile's planes in registers, exactly like scan_lazy_kernel.
 // ---------------------------------------------------------------------------------------------
-constexpr int kZoneTiles = 4;
+#ifndef SMAFA_ZONE_TILES
+#define SMAFA_ZONE_TILES 4
+#endif
+constexpr int kZoneTiles = SMAFA_ZONE_TILES;
 
-template <int PS, int PQ, int W>
-__global__ __launch_bounds__(256, 4) void scan_zone_kernel(const uint4 *__restrict__ planes,
+// Waves per SIMD the register budget must allow.  The survivor loop is a chain of dependent slow-class instructions
+// (v_readlane -> scalar-operand xor -> bcnt -> or -> cmp -> branch), so one more resident wave pays as long as the hot
+// path does not spill: measured (profiles/r02_zone_variants.txt) aa 60 columns 2.55 -> 2.45 ms at 5 waves (3.06 at 6:
+// spills), nt 60 columns 6.38 -> 5.91 ms at 6 waves.  What caps it is the dense fallback's tile (PS * W vectors).
+__host__ __device__ constexpr int zone_min_waves(int ps, int w) { return ps * w <= 4 ? 6 : ps * w <= 10 ? 5 : 4; }
+
+// FIXED: one bound for every query (a.thr == NULL, the plain --max-divergence scan).  The chunks are then staged by
+// LDS-DMA (global_load_lds_dwordx4: no register hop — the prefetch registers of the other form were being spilled
+// across every chunk, 1.2 GB of scratch writes per launch), nothing has to be merged into the records, and ~bound is a
+// scalar.  !FIXED (per-query bounds that tighten while the scan runs): register prefetch, ~bound merged at fetch time.
+template <int PS, int PQ, int W, bool FIXED>
+__global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(const uint4 *__restrict__ planes,
                                                            const uint32_t *__restrict__ qrec, ScanArgs a) {
     constexpr int T = kZoneTiles;
     constexpr int RS = qrec_stride(PQ, W);
@@ -820,6 +833,18 @@ __global__ __launch_bounds__(256, 4) void scan_zone_kernel(const uint4 *__restri
             if (idx < nqc * RV) stage[b][idx] = pre[v];
         }
     };
+    auto dma = [&](int b, uint32_t qc) {  // FIXED: global -> LDS directly; lands at wave base + lane * 16 (lane-linear)
+        const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
+        const uint4 *src = reinterpret_cast<const uint4 *>(qrec + (size_t)qc * RS);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const uint32_t idx = tid + v * 256;
+            if (idx < nqc * RV)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + idx),
+                                                 (__attribute__((address_space(3))) void *)(&stage[b][wave * 64 + v * 256]), 16, 0, 0);
+        }
+    };
+    const uint32_t nu0 = ~a.thr0;  // FIXED: every query's ~bound
     auto read_record = [&](const uint4 *rec, uint32_t(&qw)[RS]) {
 #pragma unroll
         for (int v = 0; v < RV; v++) {
@@ -863,16 +888,23 @@ __global__ __launch_bounds__(256, 4) void scan_zone_kernel(const uint4 *__restri
     };
 
     if (q0 < q1) {
-        fetch(q0);
-        commit(0, q0);
+        if (FIXED) {
+            dma(0, q0);
+        } else {
+            fetch(q0);
+            commit(0, q0);
+        }
     }
-    __syncthreads();
+    __syncthreads();  // (drains the DMA: its fence waits for vmcnt(0))
     bool filter_on = a.use_filter != 0;
     uint32_t chunk_no = 0;
     for (uint32_t qc = q0; qc < q1; qc += kChunk, buf ^= 1, chunk_no++) {
         const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
         const bool more = qc + kChunk < q1;
-        if (more) fetch(qc + kChunk);  // in flight while this chunk is computed
+        if (more) {  // in flight while this chunk is computed
+            if (FIXED) dma(buf ^ 1, qc + kChunk);  // every wave passed the barrier that ended the last use of that buffer
+            else fetch(qc + kChunk);
+        }
         if (active) {
             const bool probe = a.use_filter && (filter_on || (chunk_no & 15u) == 0);
             if (probe) {
@@ -880,7 +912,8 @@ __global__ __launch_bounds__(256, 4) void scan_zone_kernel(const uint4 *__restri
                 // ---- zone level: lane i holds [f0 f1 ~bound ..] of query i of the chunk
                 uint4 head = make_uint4(0u, 0u, 0u, 0u);  // lanes past the chunk: ~bound = 0 never passes
                 if (lane < nqc) head = stage[buf][lane * RV];
-                const uint32_t hq0 = head.x, hq1 = W > 1 ? head.y : 0u, hnu = BS == 1 ? head.y : head.z;
+                const uint32_t hq0 = head.x, hq1 = W > 1 ? head.y : 0u;
+                const uint32_t hnu = FIXED ? (lane < nqc ? nu0 : 0u) : (BS == 1 ? head.y : head.z);
                 // Tile by tile, as a RUN-TIME loop: one copy of the code below (four inlined copies of the tile
                 // fetch made the compiler hoist forty 64-bit addresses and spill them), on a copy of the tile's word.
 #pragma unroll 1
@@ -901,56 +934,29 @@ __global__ __launch_bounds__(256, 4) void scan_zone_kernel(const uint4 *__restri
 #pragma unroll
                     for (int k = 1; k < T; k++)
                         if (t == (uint32_t)k) ft = f0[k];
-#ifndef SMAFA_ZONE_VARIANT
-// A/B switches of the survivor loop (profiles/r02_zone_variants.txt).  bit 0: two survivors per iteration (two
-// dependency chains in flight): 13 % SLOWER; bit 1: the query's word from LDS, all-VGPR xors, instead of v_readlane and
-// scalar operands: 4 % slower; bit 2: opaque tile number for the rare levels (no hoisting): 6 % faster — the default.
-#define SMAFA_ZONE_VARIANT 4
-#endif
-                    auto level1 = [&](int i) -> bool {  // word 0 of the filter plane against query i of the chunk
-#if SMAFA_ZONE_VARIANT & 2
-                        const uint4 h = stage[buf][(uint32_t)i * RV];
-                        const uint32_t q0w = h.x, nu1 = BS == 1 ? h.y : h.z;
-#else
-                        const uint32_t q0w = (uint32_t)__builtin_amdgcn_readlane((int)hq0, i);
-                        const uint32_t nu1 = (uint32_t)__builtin_amdgcn_readlane((int)hnu, i);
-#endif
-                        const uint32_t u0 = __builtin_popcount(ft.x ^ q0w) + nu1;
-                        const uint32_t u1 = __builtin_popcount(ft.y ^ q0w) + nu1;
-                        const uint32_t u2 = __builtin_popcount(ft.z ^ q0w) + nu1;
-                        const uint32_t u3 = __builtin_popcount(ft.w ^ q0w) + nu1;
-                        return __ballot((int32_t)(or3(u0, u1, u2) | u3) < 0) != 0ull;
-                    };
                     while (m != 0ull) {
-#if SMAFA_ZONE_VARIANT & 1
-                        // two survivors per iteration: two independent dependency chains in flight per wave
-                        const int ia = __builtin_ctzll(m);
-                        m &= m - 1ull;
-                        const int ib = m != 0ull ? __builtin_ctzll(m) : ia;  // no second survivor: ia twice, no branch
-                        m &= m - 1ull;
-                        const bool pa = level1(ia), pb = level1(ib);
-                        const unsigned long long todo = (pa ? 1ull << ia : 0ull) | (pb ? 1ull << ib : 0ull);
-                        if (todo == 0ull) continue;
-                        m |= todo & (todo - 1ull);  // both passed (very rare): the second one goes round again
-                        const int i = __builtin_ctzll(todo);
-#else
                         const int i = __builtin_ctzll(m);
                         m &= m - 1ull;
-                        // ---- level 1: word 0 of the filter plane
-                        if (!level1(i)) continue;
-#endif
-                        const uint32_t nu = (uint32_t)__builtin_amdgcn_readlane((int)hnu, i);
-#if SMAFA_ZONE_VARIANT & 4
+                        // ---- level 1: word 0 of the filter plane.  The query's word and ~bound come out of lane i as
+                        // scalar operands.  Measured alternatives (profiles/r02_zone_variants.txt): two survivors per
+                        // iteration 13 % slower; the word via an LDS broadcast read (all-VGPR xors) 4 % slower, 16 %
+                        // slower when software-pipelined.
+                        const uint32_t q0w = (uint32_t)__builtin_amdgcn_readlane((int)hq0, i);
+                        const uint32_t nu = FIXED ? nu0 : (uint32_t)__builtin_amdgcn_readlane((int)hnu, i);
+                        const uint32_t u0 = __builtin_popcount(ft.x ^ q0w) + nu;
+                        const uint32_t u1 = __builtin_popcount(ft.y ^ q0w) + nu;
+                        const uint32_t u2 = __builtin_popcount(ft.z ^ q0w) + nu;
+                        const uint32_t u3 = __builtin_popcount(ft.w ^ q0w) + nu;
+                        if (__ballot((int32_t)(or3(u0, u1, u2) | u3) < 0) == 0ull) continue;
                         // the rare levels get the tile number through an opaque copy: otherwise the compiler hoists
-                        // their ~25 address computations out of this loop into the per-tile path every chunk pays for
+                        // their ~25 address computations out of this loop into the per-tile path every chunk pays
+                        // for (6 % of the launch)
                         uint32_t tile_r = tile;
                         asm volatile("" : "+s"(tile_r));
-#else
-                        const uint32_t tile_r = tile;
-#endif
                         // ---- level 2 (rare): the filter plane folded over all its words, words 1.. from L2/HBM
                         uint32_t qw[RS];
                         read_record(&stage[buf][(uint32_t)i * RV], qw);
+                        if (FIXED) qw[BS] = nu0;  // the staged record carries no bound in this form
                         uint32_t m0 = ft.x ^ qw[0], m1 = ft.y ^ qw[0], m2 = ft.z ^ qw[0], m3 = ft.w ^ qw[0];
                         if (W > 1) {
                             const uint4 *src = planes + (size_t)tile_r * (PS * W * 64) + (FP * W) * 64 + lane;
@@ -990,7 +996,7 @@ __global__ __launch_bounds__(256, 4) void scan_zone_kernel(const uint4 *__restri
                     for (uint32_t i = 0; i < nqc; i++, rec += RV) {
                         uint32_t qw[RS];
                         read_record(rec, qw);
-                        const uint32_t U = ~qw[BS];
+                        const uint32_t U = FIXED ? a.thr0 : ~qw[BS];
                         uint32_t d[4];
 #pragma unroll
                         for (int w = 0; w < W; w++) {
@@ -1021,8 +1027,8 @@ __global__ __launch_bounds__(256, 4) void scan_zone_kernel(const uint4 *__restri
                 load_filter();  // not kept across the walk (its registers hold the tile meanwhile): fetched again
             }
         }
-        if (more) commit(buf ^ 1, qc + kChunk);
-        __syncthreads();
+        if (more && !FIXED) commit(buf ^ 1, qc + kChunk);
+        __syncthreads();  // FIXED: also where the next chunk's DMA is waited for (vmcnt(0) in the barrier's fence)
         if (a.hits) flush_rows(a, rs, buf);
     }
     finish_rows(a);

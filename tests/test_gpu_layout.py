@@ -105,7 +105,7 @@ def test_zone_kernel_is_the_one_that_runs_when_forced(zone_env):
     store.push(s)
     got = store.scan(q, max_divergence=5)
     assert got.tobytes() == oracle.scan_codes(s, q, 5).tobytes()
-    assert store.last_scan_kernel() == "smafa::scan_zone_kernel<5, 5, 2>"
+    assert store.last_scan_kernel() == "smafa::scan_zone_kernel<5, 5, 2, true>"
     for few in (1, 3, 64):  # a handful of queries per pass: tiles fetched on demand
         one = store.scan(q[:few], max_divergence=5)
         assert one.tobytes() == oracle.scan_codes(s, q[:few], 5).tobytes()
