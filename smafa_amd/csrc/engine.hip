@@ -461,10 +461,11 @@ static double binom_tail(uint32_t bits, uint32_t bound) {
     return tail;
 }
 
-// Does the zone level pay?  An append of r rows that was sorted within itself leaves about log2(r / 256) - 1 shared
+// Does the zone level pay?  An append of r rows that was sorted within itself leaves about log2(r / 256) shared
 // leading bits per wave tile (uniform letters; related sequences share more, so the estimate is conservative);
-// unsorted appends share none.  The zone level costs ~25 % when every (query, tile) pair passes it and saves up to
-// 4-5x when few do: use it while the estimated pass rate is below one half.
+// unsorted appends share none.  Measured (tools/zone_threshold.sh, profiles/r02_zone_threshold.txt): the zone kernel
+// wins while the share of (query, tile) pairs that pass the zone level stays below ~0.6 — 1M rows at bound 5
+// (estimate 0.50): 0.51 vs 0.64 ms; 250k rows at bound 5 (0.75): 0.225 vs 0.208 ms; 10M rows at bound 7 (0.50): 5.8 vs 6.5 ms.
 static bool use_zone(const smafa_db *db, uint32_t thr0) {
     if (db->zone != 1) return db->zone == 2;
     double tiles = 0.0, pass = 0.0;
@@ -477,13 +478,12 @@ static bool use_zone(const smafa_db *db, uint32_t thr0) {
                 bits++;
                 x >>= 1;
             }
-            bits = bits > 0 ? bits - 1 : 0;
             bits = std::min(bits, std::min<uint32_t>(32u, db->L));
         }
         tiles += t;
         pass += t * binom_tail(bits, thr0);
     }
-    return tiles > 0.0 && pass / tiles < 0.5;
+    return tiles > 0.0 && pass / tiles < 0.6;
 }
 
 static uint32_t tiles_per_wave(const smafa_db *db, bool lazy) {

@@ -804,6 +804,15 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
     // scalar registers ran out, and a load per tile and chunk sits on the critical path); v_readlane hands them out
     uint4 vz = make_uint4(0u, 0u, 0u, 0u);
     if (lane < (uint32_t)T && tile0 + lane < a.tile_end) vz = a.zone[tile0 + lane];
+    // word 0's zone words go to scalar registers once (they are used by every chunk); word 1 rarely shares anything
+    // (a 10M-row store spends its ~15 shared bits in word 0): its part of the check runs only for waves that need it
+    uint32_t zc0[T], zm0[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        zc0[t] = (uint32_t)__builtin_amdgcn_readlane((int)vz.x, t);
+        zm0[t] = (uint32_t)__builtin_amdgcn_readlane((int)vz.y, t);
+    }
+    const bool zone_w1 = W > 1 && __ballot(vz.w != 0u) != 0ull;
 
     uint4 pre[NV];
     auto fetch = [&](uint32_t qc) {
@@ -914,16 +923,15 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
                 if (lane < nqc) head = stage[buf][lane * RV];
                 const uint32_t hq0 = head.x, hq1 = W > 1 ? head.y : 0u;
                 const uint32_t hnu = FIXED ? (lane < nqc ? nu0 : 0u) : (BS == 1 ? head.y : head.z);
-                // Tile by tile, as a RUN-TIME loop: one copy of the code below (four inlined copies of the tile
-                // fetch made the compiler hoist forty 64-bit addresses and spill them), on a copy of the tile's word.
-#pragma unroll 1
+                // Tile by tile, unrolled (the rare levels' address math stays inside their branch thanks to the opaque
+                // tile number below; a run-time tile loop cost 4 % on aa and 27 % on nt at bound 3 in per-tile
+                // bookkeeping — profiles/r02_zone_variants.txt).
+#pragma unroll
                 for (uint32_t t = 0; t < (uint32_t)T; t++) {
                     const uint32_t tile = tile0 + t;
                     if (tile >= a.tile_end) break;
-                    const uint32_t zc0 = (uint32_t)__builtin_amdgcn_readlane((int)vz.x, (int)t);
-                    const uint32_t zm0 = (uint32_t)__builtin_amdgcn_readlane((int)vz.y, (int)t);
-                    uint32_t u = __builtin_popcount((hq0 ^ zc0) & zm0) + hnu;
-                    if (W > 1) {
+                    uint32_t u = __builtin_popcount((hq0 ^ zc0[t]) & zm0[t]) + hnu;
+                    if (zone_w1) {
                         const uint32_t zc1 = (uint32_t)__builtin_amdgcn_readlane((int)vz.z, (int)t);
                         const uint32_t zm1 = (uint32_t)__builtin_amdgcn_readlane((int)vz.w, (int)t);
                         u += __builtin_popcount((hq1 ^ zc1) & zm1);
@@ -936,7 +944,7 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
                         if (t == (uint32_t)k) ft = f0[k];
                     while (m != 0ull) {
                         const int i = __builtin_ctzll(m);
-                        m &= m - 1ull;
+                        asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(i));  // m &= ~(1 << i) in ONE scalar op (m & (m - 1): three)
                         // ---- level 1: word 0 of the filter plane.  The query's word and ~bound come out of lane i as
                         // scalar operands.  Measured alternatives (profiles/r02_zone_variants.txt): two survivors per
                         // iteration 13 % slower; the word via an LDS broadcast read (all-VGPR xors) 4 % slower, 16 %

@@ -185,4 +185,5 @@ def test_bench_self_launch_two_ranks_one_gpu_gloo():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["verified"] is True and out["steps"] == 2
-    assert out["roofline"]["bound"] == "valu" and 0 < out["roofline"]["frac"] <= 1.0
+    frac = out["roofline"]["frac"]  # claimed only where profiles/r02_pmc.json holds counters of this workload and kernel
+    assert out["roofline"]["bound"] == "valu" and (frac is None or 0 < frac <= 1.0)
