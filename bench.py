@@ -60,6 +60,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-related", action="store_true", help="skip the related-store leg")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU time budget per CPU baseline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (tests use gloo)")
+    ap.add_argument("--collective", choices=["gather", "all_gather"], default="gather",
+                    help="how the per-rank row lists reach rank 0 each step (N > 1)")
     ap.add_argument("--single-device", action="store_true", help="testing only: every rank uses GPU 0")
     return ap.parse_args(argv)
 
@@ -241,10 +243,14 @@ def main() -> int:
     bufs = [torch.zeros(HEAD + cap * 3, dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
     d_hits, d_count = bufs[0][HEAD:], bufs[0][:2].view(torch.int64)
     if world > 1:
-        # The gather of step i runs on its own stream while the scan of step i+1 runs on the main one (two buffers);
-        # all_gather keeps every rank symmetric, rank 0 is the reader.
+        # The gather of step i runs on its own stream while the scan of step i+1 runs on the main one (two buffers).
+        # north_star: "a final RCCL gather over xGMI of the hit lists" — a gather to rank 0: every rank's [count | rows]
+        # buffer crosses its own link to the root once (--collective all_gather: the symmetric form, for comparison).
         comm = torch.cuda.Stream(device=dev)
-        gathered = [torch.zeros(world * (HEAD + cap * 3), dtype=torch.int32, device=dev) for _ in range(2)]
+        use_gather = args.collective == "gather"
+        gathered = [torch.zeros(world * (HEAD + cap * 3), dtype=torch.int32, device=dev) if (rank == 0 or not use_gather) else None
+                    for _ in range(2)]
+        gather_lists = [list(g.view(world, HEAD + cap * 3).unbind(0)) if (g is not None and use_gather) else None for g in gathered]
         scan_done = [torch.cuda.Event() for _ in range(2)]
         gather_done = [torch.cuda.Event() for _ in range(2)]
 
@@ -264,7 +270,10 @@ def main() -> int:
             scan_done[b].record(stream)
             with torch.cuda.stream(comm):
                 comm.wait_event(scan_done[b])
-                dist.all_gather_into_tensor(gathered[b], bufs[b])
+                if use_gather:
+                    dist.gather(bufs[b], gather_lists[b] if rank == 0 else None, dst=0)
+                else:
+                    dist.all_gather_into_tensor(gathered[b], bufs[b])
                 gather_done[b].record(comm)
         it[0] += 1
 
@@ -306,10 +315,13 @@ def main() -> int:
     n_rows = int(d_count.item())
     rows = sorted_rows(d_hits[: 3 * min(n_rows, cap)].cpu().numpy().view(np.uint32).reshape(-1, 3))
     checks = {"rows_fit": n_rows <= cap}
-    if world > 1:  # what the gather delivered: this rank's block must be its own buffer, every count within capacity
+    if world > 1 and gathered[last] is not None:
+        # what the gather delivered (on the root; on every rank with all_gather): this rank's block must be its own
+        # buffer, every rank's count within capacity
         g = gathered[last].view(world, HEAD + cap * 3)
         checks["gather_block_is_own_buffer"] = bool(torch.equal(g[rank], bufs[last]))
         checks["gather_counts_in_range"] = all(0 <= int(g[r][:2].view(torch.int64).item()) <= cap for r in range(world))
+        checks["gathered_rows_total"] = int(sum(int(g[r][:2].view(torch.int64).item()) for r in range(world)))
     # (1) soundness: every row's distance recomputed from the code bytes
     recomputed = (subj[rows[:, 1]] != my_q[rows[:, 0]]).sum(axis=1)
     checks["distances_recomputed"] = bool((recomputed == rows[:, 2]).all()) and bool((rows[:, 2] <= D).all())
@@ -526,7 +538,7 @@ def main() -> int:
                                 Q, max_subs, D)),
                 "db_rows": N, "seq_len": L, "alphabet": args.alphabet, "queries_per_gpu": Q, "max_divergence": D,
                 "store": args.store,
-                "parallelism": "query shards x%d, DB replicated, RCCL all_gather of row lists" % world,
+                "parallelism": "query shards x%d, DB replicated, RCCL %s of row lists to rank 0" % (world, args.collective),
             },
             "residues_per_s": value * N * L,
             "pairs_per_s": value * N,

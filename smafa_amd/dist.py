@@ -3,7 +3,7 @@
 The query loop of the reference carries no state between records except the running query number
 (/root/reference/src/lib.rs:232-318), so queries shard with NO data-path collective: the subject store is
 replicated on every GPU, rank g takes the contiguous block [g*Q/G, (g+1)*Q/G) of the query file, scans and
-selects its rows locally, and the only exchange is one gather of the finished row lists on rank 0
+selects its rows locally, and the only exchange is one gather of the finished row lists to rank 0
 (counts, then rows padded to the longest list — RCCL has no gatherv).  Blocks are contiguous and in rank
 order, so the concatenation is already in the reference's print order; the output is byte-identical for
 any number of ranks.
@@ -57,7 +57,10 @@ class HipScanner:
 
 
 def gather_rows(rows: np.ndarray, dist, device=None) -> Optional[np.ndarray]:
-    """Gather per-rank row lists (structured HIT_DTYPE arrays) on rank 0, in rank order."""
+    """Gather per-rank row lists (structured HIT_DTYPE arrays) on rank 0, in rank order: the row counts first
+    (one tiny all_gather, so that every rank knows the padded width), then ONE gather to rank 0 of the lists padded
+    to the longest (RCCL has no gatherv) — each rank's rows cross its own xGMI link to the root once, nothing goes
+    to the other ranks."""
     import torch
 
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -70,8 +73,8 @@ def gather_rows(rows: np.ndarray, dist, device=None) -> Optional[np.ndarray]:
     if len(rows):
         padded[: len(rows)] = rows.view(np.uint32).reshape(-1, 3).view(np.int32)
     mine = torch.from_numpy(padded).to(device) if device is not None else torch.from_numpy(padded)
-    parts = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine)
+    parts = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, parts, dst=0)
     if rank != 0:
         return None
     out = [p.cpu().numpy().view(np.uint32).reshape(-1, 3)[:c] for p, c in zip(parts, counts)]

@@ -10,7 +10,7 @@ OUT=${OUT:-/tmp/asan}
 mkdir -p "$OUT"
 make -C "$ROOT/smafa_amd/csrc" -j8 >/dev/null
 cd "$ROOT/smafa_amd/csrc"
-for f in common alphabet fastx dbfile select drivers; do
+for f in common alphabet fastx dbfile select packed drivers; do
   g++ -O1 -g -std=c++17 -fPIC -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -c host/$f.cpp -o "$OUT/$f.o"
 done
 g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined -c host/main.cpp -o "$OUT/main.o"
@@ -39,13 +39,31 @@ for f in sorted(os.listdir(G)):
     else:
         run("makedb", "-i", p, "-d", out + "/g.db"); run("count", "-i", p); run("cluster", "-i", p, "-d", "2")
         run("query", "-d", out + "/g.db", "-q", p)
+rng = random.Random(5)
 synth.write_fasta(out + "/big.fna", synth.subjects(1_200_000, 60, 0, seed=2, n_frac=0.001), 0)
 synth.write_fasta(out + "/small.fna", synth.subjects(300, 70, 0, seed=3, n_frac=0.01), 0)
 run("makedb", "-i", out + "/big.fna", "-d", out + "/big.db"); run("query", "-d", out + "/big.db", "-q", out + "/small.fna")
 run("cluster", "-i", out + "/big.fna", "-d", "3"); run("count", "-i", out + "/big.fna")
 run("makedb", "-i", out + "/small.fna", "-d", out + "/small.db")
+# the threaded FASTQ / gzip loaders (>= 32 MB after decompression), whole and truncated
+import gzip
+rows = synth.subjects(560_000, 60, 0, seed=4, n_frac=0.001)
+letters = b"ACGTN"
+fq = b"".join(b"@r%d\n" % i + bytes(letters[c] for c in r) + b"\n+\n" + (b"@" if i % 4 == 0 else b"I") * 60 + b"\n" for i, r in enumerate(rows[:340_000]))
+open(out + "/big.fq", "wb").write(fq); open(out + "/big.fq.gz", "wb").write(gzip.compress(fq, 1))
+open(out + "/cut.fq", "wb").write(fq[: len(fq) - 37]); open(out + "/cut.fq.gz", "wb").write(gzip.compress(fq, 1)[:-4000])
+for f in ("big.fq", "big.fq.gz", "cut.fq", "cut.fq.gz"):
+    run("makedb", "-i", out + "/" + f, "-d", out + "/fq.db"); run("count", "-i", out + "/" + f)
+# a packed store header over garbage: the loader must refuse it before anything is indexed
+import struct
+hdr = b"\x03\x02SMAFA\x00" + struct.pack("<4I11Q", 0, 60, 2, 2, 1000, 4, 1, 4096, 8192, 12288, 16384, 20480, 24576, 28672, 28672 + 4 * 2 * 2 * 256 * 4)
+for cut in (len(hdr), 4096, 20000, 40000):
+    open(out + "/p.db", "wb").write((hdr + bytes(60000))[:cut]); run("query", "-d", out + "/p.db", "-q", out + "/small.fna")
+for _ in range(100):
+    d = bytearray(hdr + bytes(range(256)) * 200)
+    for _ in range(rng.randint(1, 6)): d[rng.randrange(8, 8 + 120)] = rng.randrange(256)
+    open(out + "/p.db", "wb").write(bytes(d)); run("query", "-d", out + "/p.db", "-q", out + "/small.fna")
 db = open(out + "/small.db", "rb").read(); fa = open(out + "/small.fna", "rb").read()
-rng = random.Random(5)
 cases = [db[:n] for n in list(range(60)) + list(range(60, len(db), 97)) + [len(db) - 1]]
 for _ in range(300):
     d = bytearray(db)

@@ -24,7 +24,8 @@ oracle.build()
 t_end, rounds, scans = time.time() + budget, 0, 0
 SWITCHES = {"SMAFA_FILTER": ["1", "1", "1", "0"], "SMAFA_LAZY": ["1", "1", "0"], "SMAFA_TILES": ["", "1", "2", "4"],
             "SMAFA_NT_PLANES": ["", "", "3"], "SMAFA_WIDE_FROM": ["5", "5", "3"], "SMAFA_WIDE_ONE": ["1", "1", "0"],
-            "SMAFA_TWO_PHASE": ["1", "1", "0"], "SMAFA_COUNT_FIRST_K": ["3", "3", "2", "1000000"]}
+            "SMAFA_TWO_PHASE": ["1", "1", "0"], "SMAFA_COUNT_FIRST_K": ["3", "3", "2", "1000000"],
+            "SMAFA_ZONE": ["1", "1", "2", "2", "0"], "SMAFA_SORT": ["1", "1", "0"], "SMAFA_LAYOUT": ["1", "1", "0"]}
 print("soak seed", seed0, flush=True)
 while time.time() < t_end:
     rng = np.random.default_rng(seed0 + rounds)
@@ -32,7 +33,7 @@ while time.time() < t_end:
     alphabet = int(rng.integers(0, 2))
     n_letters = int(rng.choice([2, 4, 5] if alphabet == 0 else [2, 4, 20, 28]))
     L = int(rng.choice([1, 2, 7, 12, 20, 31, 32, 33, 60, 60, 60, 64, 65, 90, 96, 128, 129, 150, 200, 257]))
-    n = int(rng.choice([1, 3, 255, 256, 257, 1000, 4097, 20000]))
+    n = int(rng.choice([1, 3, 255, 256, 257, 1000, 4097, 9000, 20000]))
     nq = int(rng.choice([1, 2, 17, 64, 65, 300]))
     env = {k: str(rng.choice(v)) for k, v in SWITCHES.items()}
     for k, v in env.items():
