@@ -4,7 +4,7 @@
 Metric (BASELINE.json): query seqs/sec (+ DB residues/sec) vs the roofline, 10M x 60-aa DB, d <= 5.
 A "step" = one pass of the hot path over one batch: every query of the batch (default 10 000 per GPU)
 scanned against the whole resident subject store, qualifying rows appended on the device, and — when
-more than one GPU takes part — the per-rank row lists gathered over RCCL.  The packed subject block and the
+more than one GPU takes part — the per-rank row lists gathered on rank 0 over RCCL.  The packed subject block and the
 packed query batch are resident in HBM before the timed region starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -373,46 +373,55 @@ def main() -> int:
     stream_info = None
     if side_legs:
         one = smafa_amd.QuerySet(store, my_q[:1])
-        for _ in range(3):
-            store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 200
-        e0.record(stream)
-        for _ in range(reps):
-            store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps  # everything one query costs on the stream: launches, gaps, row bookkeeping
-        k_ms, launches = [], 0
-        for _ in range(20):  # kernel-only time: HIP events recorded by the library right around the scan kernel
-            store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
-            m, launches = store.last_scan_ms()
-            k_ms.append(m)
-        k_med = float(np.median(k_ms))
-        splan = store.last_scan_plan()
-        # bytes one pass streams: the whole block, or only the prefilter's plane when that is all that is resident
-        sb = info.words_per_plane * 4 if splan["filter_plane_resident"] else info.bytes_per_subject
+
+        def one_query_pass():
+            for _ in range(3):
+                store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 200
+            e0.record(stream)
+            for _ in range(reps):
+                store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
+            e1.record(stream)
+            torch.cuda.synchronize()
+            wall = e0.elapsed_time(e1) / reps  # everything one query costs on the stream: launches, gaps, row bookkeeping
+            k_ms, launches = [], 0
+            for _ in range(20):  # kernel-only time: HIP events recorded by the library right around the scan kernel
+                store.scan_launch(one, D, None, d_hits.data_ptr(), cap, d_count.data_ptr())
+                m, launches = store.last_scan_ms()
+                k_ms.append(m)
+            return wall, float(np.median(k_ms)), launches, store.last_scan_kernel(), store.last_scan_plan(), int(d_count.item())
+
+        # (a) the shipped form: on a sorted store a pass reads the zone words (16 B per 256 subjects) and fetches only the
+        #     tiles the query survives; (b) zone level off: every pass streams the prefilter's whole bit-plane — the
+        #     HBM-bound form the streamed fractions below are for
+        wall_z, k_z, launches_z, kern_z, plan_z, rows_z = one_query_pass()
+        store.set_zone_level(0)
+        wall_s, k_s1, launches_s, kern_s, plan_s, rows_s = one_query_pass()
+        store.set_zone_level(1)
+        sb = info.words_per_plane * 4 if plan_s["filter_plane_resident"] else info.bytes_per_subject
         streamed = info.hbm_bytes * sb / info.bytes_per_subject
         alg = N * L * (8 if args.alphabet == "aa" else int(info.planes)) / 8
         ceiling = smafa_amd.hbm_read_probe(local_rank, 8 << 30)
         stream_info = {
-            "kernel": store.last_scan_kernel(),
-            "ms_per_query_wall": ms,
-            "kernel_ms_median": k_med,
-            "launches_per_query": launches,
-            "streamed_bytes_per_subject": int(sb),
-            "frac_kernel_streamed": streamed / k_med / 1e6 / HBM_PEAK_GBS,
-            "frac_wall_streamed": streamed / ms / 1e6 / HBM_PEAK_GBS,
-            "algorithmic_x_of_peak": alg / k_med / 1e6 / HBM_PEAK_GBS,
-            "kernel_streamed_GBs": streamed / k_med / 1e6,
+            "shipped": {"kernel": kern_z, "ms_per_query_wall": wall_z, "kernel_ms_median": k_z, "launches_per_query": launches_z,
+                        "algorithmic_x_of_peak": alg / k_z / 1e6 / HBM_PEAK_GBS, "rows": rows_z},
+            "streaming": {"kernel": kern_s, "ms_per_query_wall": wall_s, "kernel_ms_median": k_s1, "launches_per_query": launches_s,
+                          "streamed_bytes_per_subject": int(sb),
+                          "frac_kernel_streamed": streamed / k_s1 / 1e6 / HBM_PEAK_GBS,
+                          "frac_wall_streamed": streamed / wall_s / 1e6 / HBM_PEAK_GBS,
+                          "algorithmic_x_of_peak": alg / k_s1 / 1e6 / HBM_PEAK_GBS,
+                          "kernel_streamed_GBs": streamed / k_s1 / 1e6, "rows": rows_s},
+            "rows_identical": rows_z == rows_s,
             "empirical_read_ceiling_GBs": ceiling,
             "empirical_read_ceiling_frac_of_peak": ceiling / HBM_PEAK_GBS,
-            "plan": splan,
-            "note": "one query per store pass. frac_kernel_streamed / frac_wall_streamed = bytes the kernel actually "
-                    "reads per pass (the prefilter's bit-plane only when the other planes are fetched on demand) over "
-                    "kernel time / wall time per query, as a fraction of 8 TB/s; algorithmic_x_of_peak = %g B/subject "
-                    "over kernel time (a reuse figure, not an efficiency); empirical ceiling = smafa_hbm_read_probe, a "
-                    "trivial sum over 8 GiB on this box" % (alg / N),
+            "note": "one query per store pass. `shipped`: the default path (zone level: only the tiles the query survives "
+                    "are fetched, so the pass is not a stream of the store and no streamed fraction is claimed for it). "
+                    "`streaming`: the same pass with the zone level off (smafa_set_zone_level 0) — the kernel streams the "
+                    "prefilter's bit-plane of every subject: frac_kernel_streamed / frac_wall_streamed = those bytes over "
+                    "kernel time / wall time per query as a fraction of 8 TB/s; algorithmic_x_of_peak = %g B/subject over "
+                    "kernel time (a reuse figure, not an efficiency); empirical ceiling = smafa_hbm_read_probe, a trivial "
+                    "sum over 8 GiB on this box" % (alg / N),
         }
         one.close()
 

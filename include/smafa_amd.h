@@ -136,7 +136,10 @@ void smafa_qset_destroy(smafa_qset *qs);
 /*
  * Asynchronous scan of a resident query set against the resident store on the handle's stream.
  * d_hits: device buffer of cap smafa_hit rows (unordered on return); d_count: device uint64 that
- * receives the number of qualifying rows (may exceed cap; only the first cap are stored).
+ * receives the number of qualifying rows — exact at any capacity with a fixed bound (max_num_hits absent): it may
+ * exceed cap, only the first cap rows to arrive are stored, and a caller can size its buffer from it.  In the
+ * tightening modes (max_num_hits = k) a value above cap only says "did not fit".  A fixed-bound scan is ONE kernel
+ * launch; nothing has to be reset between calls.
  * max_div / max_num_hits as in smafa_scan_hits, except that rows above kth(query) may remain: rows are kept
  * when dist <= the device's final bound of their query, which is exact for k = 1 and >= kth(query) for k >= 2.
  */
@@ -158,6 +161,11 @@ int smafa_set_query_block(smafa_db *db, uint32_t queries_per_block);
 /* 1 (default): the scan evaluates an exact lower bound first and runs the full comparison only where it can
  * still qualify; 0: every (query, subject) pair gets the full comparison.  Results are identical either way. */
 int smafa_set_prefilter(smafa_db *db, int enabled);
+/* The zone level of a sorted store (scan_zone_kernel: a lower bound on the distances of all 256 subjects of a wave tile
+ * at once, from the filter bits they share): 1 (default) = where the store's sorted runs make it prune, 0 = never (every
+ * pass streams the prefilter's plane: the HBM-bound form), 2 = whenever the filter-plane-resident kernel runs.  Results
+ * are identical in every mode. */
+int smafa_set_zone_level(smafa_db *db, int mode);
 
 /* -------------------------------------------------------- host-side selection */
 /*

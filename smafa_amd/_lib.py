@@ -26,7 +26,7 @@ EXPORTS = [
     "smafa_last_error", "smafa_device_count", "smafa_set_verbosity", "smafa_encode", "smafa_decode",
     "smafa_db_create", "smafa_db_append", "smafa_db_save", "smafa_db_load", "smafa_db_info", "smafa_db_set_stream", "smafa_db_destroy",
     "smafa_scan_hits", "smafa_distances", "smafa_qset_create", "smafa_qset_destroy", "smafa_scan_launch",
-    "smafa_sync", "smafa_last_scan_ms", "smafa_last_scan_plan", "smafa_last_scan_kernel", "smafa_build_id", "smafa_hbm_read_probe", "smafa_set_query_block", "smafa_set_prefilter", "smafa_select_rows", "smafa_write_rows",
+    "smafa_sync", "smafa_last_scan_ms", "smafa_last_scan_plan", "smafa_last_scan_kernel", "smafa_build_id", "smafa_hbm_read_probe", "smafa_set_query_block", "smafa_set_prefilter", "smafa_set_zone_level", "smafa_select_rows", "smafa_write_rows",
     "smafa_dbfile_write", "smafa_dbfile_read", "smafa_fastx_load", "smafa_free",
     "smafa_makedb", "smafa_makedb_packed", "smafa_query", "smafa_query_multi", "smafa_cluster", "smafa_cluster_sharded", "smafa_count",
 ]
@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
     l.smafa_hbm_read_probe.argtypes = [C.c_int, C.c_uint64, C.POINTER(C.c_double)]
     l.smafa_set_query_block.argtypes = [vp, C.c_uint32]
     l.smafa_set_prefilter.argtypes = [vp, C.c_int]
+    l.smafa_set_zone_level.argtypes = [vp, C.c_int]
     l.smafa_select_rows.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_uint32, vp, C.c_uint64, u64p]
     l.smafa_write_rows.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_int]

@@ -161,6 +161,9 @@ class SubjectStore:
     def set_prefilter(self, enabled: bool) -> None:
         check(lib().smafa_set_prefilter(self._h, 1 if enabled else 0))
 
+    def set_zone_level(self, mode: int) -> None:
+        check(lib().smafa_set_zone_level(self._h, int(mode)))
+
     def scan_launch(self, qset: QuerySet, max_divergence: Optional[int], max_num_hits: Optional[int],
                     d_hits: int, cap: int, d_count: int) -> None:
         check(lib().smafa_scan_launch(self._h, qset._h, _opt(max_divergence), _opt(max_num_hits),

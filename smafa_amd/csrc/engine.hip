@@ -1237,6 +1237,12 @@ const char *smafa_build_id(void) {
 #endif
 }
 
+int smafa_set_zone_level(smafa_db *db, int mode) {
+    if (!db || mode < 0 || mode > 2) return set_error(SMAFA_ERR_INVALID, "smafa_set_zone_level: bad argument");
+    db->zone = mode;
+    return SMAFA_OK;
+}
+
 int smafa_set_prefilter(smafa_db *db, int enabled) {
     if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_set_prefilter: NULL handle");
     db->use_filter = enabled != 0;

@@ -14,25 +14,26 @@
 //
 // HBM layout of the subject block ("wave tile" = 256 subjects = 64 lanes x 4):
 //     u32 planes[n_wave_tiles][P][W][256]      W = ceil(seq_len / 32)
-// element [t][p][w][i] = word w of plane p of subject t*256 + i.  A lane owns subjects
+// element [t][p][w][i] = word w of plane p of the subject at POSITION t*256 + i.  A lane owns positions
 // 4*lane .. 4*lane+3 of its wave's tile, so every load is one 16-byte global_load_dwordx4 per
-// lane, 1 KiB contiguous per wave instruction; what a wave needs of its tiles is read once per query
-// block and then lives in VGPRs while the wave walks the block (all planes: scan_kernel; only the
-// prefilter's plane, the rest on demand: scan_lazy_kernel).
+// lane, 1 KiB contiguous per wave instruction.
+// Three free parameters of that layout are chosen for the prefilter and change no result (a distance counts columns
+// whose codes differ): the COLUMN ORDER (most informative columns first), a PER-COLUMN RE-CODING of the symbols (plane 0
+// = the best-balanced split of the column's letters: it is the plane every lower bound looks at) — both applied by
+// pack_rows_kernel to subjects and queries alike — and the SUBJECT ORDER: big appends are sorted by their filter words,
+// order[position] maps back to the subject index, and zone[tile] records the filter bits the 256 subjects of a tile
+// share (scan_zone_kernel's first level).  See DESIGN.md §2.
 //
 // Query records (u32 words, stride qrec_stride(P, W)):
 //     [ filter word 0 | filter word 1 | bound slot | filter words 2..W-1 | the other planes' words ]
 // (one-word records: [ filter word 0 | bound slot | ... ]) — see qslot() / bound_slot().
 // The 4 waves of a workgroup walk the same query block, so they stage 64 records at a time in LDS
-// (double-buffered, one barrier per 64 queries) and every wave broadcast-reads a record into VGPRs with
-// ds_read_b128 (all lanes read one address: conflict-free).  Why not scalar registers: measured on
-// MI355X (profiles/r01_ubench_valu*.txt) v_xor / v_add / v_bitop3 with all-VGPR sources issue at
-// ~60 T lane-ops/s chip-wide, while the same ops with an SGPR source — and v_bcnt, v_min, v_cmp, v_or3
-// regardless of sources — issue at ~37 T.  The hot loop is therefore built from all-VGPR bitop3/xor,
-// as few popcounts as exactness allows, and a single compare per wave step.
+// (double-buffered, one barrier per 64 queries).  Measured on MI355X (profiles/r01_ubench_valu*.txt) v_xor / v_add /
+// v_bitop3 with all-VGPR sources issue at ~60 T lane-ops/s chip-wide, while the same ops with an SGPR source — and
+// v_bcnt, v_min, v_cmp, v_or3, v_readlane regardless of sources — issue at ~37 T.
 //
-// Hits are rare (thresholded), so the append is a wave-aggregated atomic (v_mbcnt + s_bcnt1 + one
-// global_atomic_add per wave, emitted by hipcc for atomicAdd(p, 1)).
+// Hits are rare (thresholded): rows are parked in an LDS stage per workgroup and written out with one global
+// reservation per 64-query chunk (RowStage, emit, flush_rows, finish_rows).
 #pragma once
 
 #include <hip/hip_runtime.h>
