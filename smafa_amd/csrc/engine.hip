@@ -100,7 +100,12 @@ struct smafa_db {
     uint32_t *d_order = nullptr;  // position -> subject index (cap_tiles * 256 entries)
     uint4 *d_zone = nullptr;      // per wave tile: shared filter bits (cap_tiles entries)
     struct Run { uint64_t rows; bool sorted; };
-    std::vector<Run> runs;        // the appends the store consists of (each sorted within itself or not)
+    std::vector<Run> runs;        // the appends the store consists of (each sorted within itself or not); kept in the packed file
+    // What the zone level can prune with, MEASURED: shared filter bits per wave tile (both words), read back after every
+    // append; hist[b] = tiles sharing b bits.  Sorting gives ~log2(rows / 256) on unrelated sequences, related ones share
+    // more, many small appends share few — use_zone() works from this, not from assumptions about the data.
+    std::vector<uint8_t> tile_bits;
+    uint64_t zone_hist[65] = {0};
     int zone = 1;                 // zone level of the filter-plane-resident kernel: 1 = where it prunes (use_zone), 0 = never
                                   // (SMAFA_ZONE=0), 2 = whenever that kernel runs (SMAFA_ZONE=2, tests)
     bool sort_rows = true;        // sort big appends by their filter words (SMAFA_SORT=0: keep the append order)
@@ -228,6 +233,18 @@ static void launch_pack(smafa_db *db, const uint8_t *d_codes, const uint32_t *d_
                        d_out, mode, db->QS, db->d_perm.as<uint16_t>(), db->d_tab.as<uint8_t>(), d_order);
 }
 
+// fold the zone words of tiles [t0, t0 + count) into the store's shared-bit statistics (a re-computed tile replaces its
+// earlier entry)
+static void note_zone_words(smafa_db *db, uint32_t t0, const uint4 *z, size_t count) {
+    if (db->tile_bits.size() < (size_t)t0 + count) db->tile_bits.resize((size_t)t0 + count, 255);
+    for (size_t i = 0; i < count; i++) {
+        uint8_t &slot = db->tile_bits[t0 + i];
+        if (slot != 255) db->zone_hist[slot]--;
+        slot = (uint8_t)(__builtin_popcount(z[i].y) + __builtin_popcount(z[i].w));
+        db->zone_hist[slot]++;
+    }
+}
+
 constexpr uint64_t kSortMin = 4096;  // appends of fewer rows keep their order (their tiles share few bits anyway)
 
 // Upload code rows and pack them with the ballot kernel.  mode 0: subjects, at positions first.. of the store — big
@@ -277,6 +294,10 @@ static int pack_rows(smafa_db *db, const uint8_t *codes, uint64_t first, uint64_
                            reinterpret_cast<const uint4 *>(db->d_planes), db->P, db->W, t0, t1, (uint32_t)(first + n), db->d_zone);
         HIP_TRY(hipGetLastError());
         db->runs.push_back({n, sorted});
+        std::vector<uint4> z(t1 - t0);
+        HIP_TRY(hipMemcpyAsync(z.data(), db->d_zone + t0, z.size() * sizeof(uint4), hipMemcpyDeviceToHost, db->stream));
+        HIP_TRY(hipStreamSynchronize(db->stream));
+        note_zone_words(db, t0, z.data(), z.size());
     }
     // the caller's host buffer is borrowed for the call only, and `upload` is reused by the next call
     HIP_TRY(hipStreamSynchronize(db->stream));
@@ -461,27 +482,18 @@ static double binom_tail(uint32_t bits, uint32_t bound) {
     return tail;
 }
 
-// Does the zone level pay?  An append of r rows that was sorted within itself leaves about log2(r / 256) shared
-// leading bits per wave tile (uniform letters; related sequences share more, so the estimate is conservative);
-// unsorted appends share none.  Measured (tools/zone_threshold.sh, profiles/r02_zone_threshold.txt): the zone kernel
-// wins while the share of (query, tile) pairs that pass the zone level stays below ~0.6 — 1M rows at bound 5
-// (estimate 0.50): 0.51 vs 0.64 ms; 250k rows at bound 5 (0.75): 0.225 vs 0.208 ms; 10M rows at bound 7 (0.50): 5.8 vs 6.5 ms.
+// Does the zone level pay?  A tile that shares b filter bits lets a query unrelated to it through with probability
+// P(Binomial(b, 1/2) <= bound); the expected share of (query, tile) pairs that pass follows from the store's measured
+// shared-bit histogram (zone_hist).  Measured (tools/zone_threshold.sh, profiles/r02_zone_threshold.txt): the zone
+// kernel wins while that share stays below ~0.6 — 1M rows at bound 5 (~12 bits, 0.39): 0.51 vs 0.64 ms; 250k rows at
+// bound 5 (~10 bits, 0.62): 0.225 vs 0.208 ms; 10M rows at bound 7 (~15 bits, 0.50): 5.8 vs 6.5 ms.
 static bool use_zone(const smafa_db *db, uint32_t thr0) {
     if (db->zone != 1) return db->zone == 2;
     double tiles = 0.0, pass = 0.0;
-    for (const smafa_db::Run &r : db->runs) {
-        const double t = (double)r.rows / kWaveTile;
-        uint32_t bits = 0;
-        if (r.sorted) {
-            uint64_t x = r.rows / kWaveTile;
-            while (x > 1) {
-                bits++;
-                x >>= 1;
-            }
-            bits = std::min(bits, std::min<uint32_t>(32u, db->L));
-        }
-        tiles += t;
-        pass += t * binom_tail(bits, thr0);
+    for (uint32_t b = 0; b <= 64; b++) {
+        if (!db->zone_hist[b]) continue;
+        tiles += (double)db->zone_hist[b];
+        pass += (double)db->zone_hist[b] * binom_tail(b, thr0);
     }
     return tiles > 0.0 && pass / tiles < 0.6;
 }
@@ -864,6 +876,8 @@ int db_clear(smafa_db *db) {
     if (!db) return set_error(SMAFA_ERR_INVALID, "db_clear: NULL handle");
     db->n = 0;
     db->runs.clear();
+    db->tile_bits.clear();
+    for (uint64_t &h : db->zone_hist) h = 0;
     db->generation++;
     return SMAFA_OK;
 }
@@ -1001,6 +1015,7 @@ int db_load_packed(smafa_db **out, int device, const PackedStore &pk) {
     if (e != hipSuccess) return fail(set_error(SMAFA_ERR_DEVICE, "loading the packed store failed: %s", hipGetErrorString(e)));
     db->n = pk.h.n;
     for (uint64_t r = 0; r < pk.h.n_runs; r++) db->runs.push_back({pk.runs[2 * r], pk.runs[2 * r + 1] != 0});
+    note_zone_words(db, 0, reinterpret_cast<const uint4 *>(pk.zone), pk.h.n_tiles);
     db->generation++;
     return SMAFA_OK;
 }
