@@ -106,6 +106,7 @@ struct smafa_db {
     // more, many small appends share few — use_zone() works from this, not from assumptions about the data.
     std::vector<uint8_t> tile_bits;
     uint64_t zone_hist[65] = {0};
+    double zone_loose = 0.3;      // pass share below which the zone kernel also takes bounds level 1 cannot prune at (SMAFA_ZONE_LOOSE)
     int zone = 1;                 // zone level of the filter-plane-resident kernel: 1 = where it prunes (use_zone), 0 = never
                                   // (SMAFA_ZONE=0), 2 = whenever that kernel runs (SMAFA_ZONE=2, tests)
     bool sort_rows = true;        // sort big appends by their filter words (SMAFA_SORT=0: keep the append order)
@@ -487,15 +488,23 @@ static double binom_tail(uint32_t bits, uint32_t bound) {
 // shared-bit histogram (zone_hist).  Measured (tools/zone_threshold.sh, profiles/r02_zone_threshold.txt): the zone
 // kernel wins while that share stays below ~0.6 — 1M rows at bound 5 (~12 bits, 0.39): 0.51 vs 0.64 ms; 250k rows at
 // bound 5 (~10 bits, 0.62): 0.225 vs 0.208 ms; 10M rows at bound 7 (~15 bits, 0.50): 5.8 vs 6.5 ms.
-static bool use_zone(const smafa_db *db, uint32_t thr0) {
-    if (db->zone != 1) return db->zone == 2;
+static double zone_pass_share(const smafa_db *db, uint32_t thr0) {
     double tiles = 0.0, pass = 0.0;
     for (uint32_t b = 0; b <= 64; b++) {
         if (!db->zone_hist[b]) continue;
         tiles += (double)db->zone_hist[b];
         pass += (double)db->zone_hist[b] * binom_tail(b, thr0);
     }
-    return tiles > 0.0 && pass / tiles < 0.6;
+    return tiles > 0.0 ? pass / tiles : 1.0;
+}
+
+// `prunes`: does level 1 (word 0 of the filter plane) prune at this bound (prefilter_prunes)?  Where it does not — short
+// sequences, loose bounds: every (query, tile) pair that passes the zone level goes on to the exact comparison — the
+// zone level has to exclude more on its own to beat the all-planes kernel: SMAFA_ZONE_LOOSE (default 0.3).
+static bool use_zone(const smafa_db *db, uint32_t thr0, bool prunes) {
+    if (!db->lazy || !db->use_filter || db->W > 4) return false;
+    if (db->zone != 1) return db->zone == 2;
+    return zone_pass_share(db, thr0) < (prunes ? 0.6 : db->zone_loose);
 }
 
 static uint32_t tiles_per_wave(const smafa_db *db, bool lazy) {
@@ -531,7 +540,7 @@ static void launch_wide_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
 
 static void launch_scan(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid, uint32_t T,
                         bool lazy, bool zone) {
-    if (lazy && (db->W >= db->wide_from || (db->W == 1 && db->wide_one))) {  // above 64 columns, or up to 32
+    if (lazy && !zone && (db->W >= db->wide_from || (db->W == 1 && db->wide_one))) {  // above 64 columns, or up to 32
         if (db->P == 2) return launch_wide_t<2, 3>(db, d_qrec, a, grid);
         if (db->P == 3) return launch_wide_t<3, 3>(db, d_qrec, a, grid);
         return launch_wide_t<5, 5>(db, d_qrec, a, grid);
@@ -597,9 +606,12 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     ScanArgs a;
     const bool specialised = db->W <= 4;  // else scan_wide_kernel / scan_generic_kernel
     const bool wide = use_wide(db, thr0);
-    const bool lazy = wide || (specialised && use_lazy(db, thr0));
+    bool lazy = wide || (specialised && use_lazy(db, thr0));
     const bool seed = d_rows == nullptr && k_tight == 1;  // the seed pass covers a few tiles: no zone level
-    const bool zone = lazy && !wide && !seed && use_zone(db, thr0);
+    // a sorted store whose tiles share enough bits takes the zone kernel at any length up to 128 columns — also where
+    // scan_wide_kernel would otherwise run (one-word stores)
+    const bool zone = specialised && !seed && use_zone(db, thr0, prefilter_prunes(db, thr0));
+    lazy = lazy || zone;  // (the plan reported by smafa_last_scan_plan: a filter-plane-resident kernel)
     const uint32_t T = zone ? (uint32_t)kZoneTiles
                      : wide ? (uint32_t)kWideTiles : specialised ? tiles_per_wave(db, lazy) : (uint32_t)kGenericTiles;
     a.tile_begin = tile_begin;
@@ -1066,6 +1078,7 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     if (const char *wv = getenv("SMAFA_WIDE_FROM")) db->wide_from = (uint32_t)std::max(3, atoi(wv));
     if (const char *zv = getenv("SMAFA_ZONE")) db->zone = std::min(2, std::max(0, atoi(zv)));
     if (const char *sv = getenv("SMAFA_SORT")) db->sort_rows = atoi(sv) != 0;
+    if (const char *zl = getenv("SMAFA_ZONE_LOOSE")) db->zone_loose = atof(zl);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) db->n_cu = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&db->own_stream, hipStreamNonBlocking);

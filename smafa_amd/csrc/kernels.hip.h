@@ -991,7 +991,9 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
                         stream_compare(tile_r, qw, qc + (uint32_t)i);
                     }
                 }
-                filter_on = passes * 4u <= nqc;
+                // an exact comparison from L2 costs ~60 VALU per (query, tile) pair, the dense walk below ~25 for EVERY
+                // pair of the chunk (4 tiles x nqc): switch when more than ~2/5 of the pairs got that far
+                filter_on = passes * 5u <= nqc * 8u;
             } else {
                 // dense neighbourhoods: one pass over the chunk per tile, that tile's planes in registers
                 for (uint32_t t = 0; t < (uint32_t)T; t++) {
