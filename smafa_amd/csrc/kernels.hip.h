@@ -949,7 +949,7 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
                         // ---- level 1: word 0 of the filter plane.  The query's word and ~bound come out of lane i as
                         // scalar operands.  Measured alternatives (profiles/r02_zone_variants.txt): two survivors per
                         // iteration 13 % slower; the word via an LDS broadcast read (all-VGPR xors) 4 % slower, 16 %
-                        // slower when software-pipelined.
+                        // slower when software-pipelined; the word copied to a VGPR first (v_mov, all-VGPR xors): no change.
                         const uint32_t q0w = (uint32_t)__builtin_amdgcn_readlane((int)hq0, i);
                         const uint32_t nu = FIXED ? nu0 : (uint32_t)__builtin_amdgcn_readlane((int)hnu, i);
                         const uint32_t u0 = __builtin_popcount(ft.x ^ q0w) + nu;
