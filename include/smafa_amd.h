@@ -198,6 +198,10 @@ int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t
  * parse_fastx_file + from_bytes per record (src/lib.rs:221,235).  Fails like the reference on a byte outside
  * the alphabet (message of src/lib.rs:38-41); records of unequal length fail with SMAFA_ERR_PANIC. */
 int smafa_fastx_load(const char *path, int alphabet, uint8_t **codes, uint64_t *n, uint32_t *seq_len);
+/* The same, stopping quietly at the first offending record: returns the rows before it, and in *pending the code
+ * smafa_fastx_load would have failed with (message in smafa_last_error()) or SMAFA_OK.  For hosts that — like the
+ * reference's loop, src/lib.rs:232-318 — answer the queries in front of a bad record before they fail. */
+int smafa_fastx_load_partial(const char *path, int alphabet, uint8_t **codes, uint64_t *n, uint32_t *seq_len, int *pending);
 void smafa_free(void *p);
 
 /* ------------------------------------------- drivers: the crate's pub fns */

@@ -27,7 +27,7 @@ EXPORTS = [
     "smafa_db_create", "smafa_db_append", "smafa_db_save", "smafa_db_load", "smafa_db_info", "smafa_db_set_stream", "smafa_db_destroy",
     "smafa_scan_hits", "smafa_distances", "smafa_qset_create", "smafa_qset_destroy", "smafa_scan_launch",
     "smafa_sync", "smafa_last_scan_ms", "smafa_last_scan_plan", "smafa_last_scan_kernel", "smafa_build_id", "smafa_hbm_read_probe", "smafa_set_query_block", "smafa_set_prefilter", "smafa_set_zone_level", "smafa_select_rows", "smafa_write_rows",
-    "smafa_dbfile_write", "smafa_dbfile_read", "smafa_fastx_load", "smafa_free",
+    "smafa_dbfile_write", "smafa_dbfile_read", "smafa_fastx_load", "smafa_fastx_load_partial", "smafa_free",
     "smafa_makedb", "smafa_makedb_packed", "smafa_query", "smafa_query_multi", "smafa_cluster", "smafa_cluster_sharded", "smafa_count",
 ]
 
@@ -108,6 +108,7 @@ def lib() -> C.CDLL:
     l.smafa_dbfile_write.argtypes = [C.c_char_p, C.c_int, vp, C.c_uint64, C.c_uint32]
     l.smafa_dbfile_read.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(vp), u64p, u32p]
     l.smafa_fastx_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), u64p, u32p]
+    l.smafa_fastx_load_partial.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), u64p, u32p, C.POINTER(C.c_int)]
     l.smafa_free.argtypes = [vp]
     l.smafa_free.restype = None
     l.smafa_makedb.argtypes = [C.c_char_p, C.c_char_p, C.c_int]

@@ -241,6 +241,22 @@ def load_fastx(path: str, alphabet: int = ALPHABET_NT) -> np.ndarray:
     return arr.reshape(n.value, L.value)
 
 
+def load_fastx_partial(path: str, alphabet: int = ALPHABET_NT):
+    """-> (code rows in front of the first offending record, None or the SmafaError that record raises)"""
+    ptr, n, L, pending = C.c_void_p(), C.c_uint64(0), C.c_uint32(0), C.c_int(0)
+    check(lib().smafa_fastx_load_partial(os.fsencode(path), alphabet, C.byref(ptr), C.byref(n), C.byref(L), C.byref(pending)))
+    err = None
+    if pending.value != _lib.OK:
+        msg = lib().smafa_last_error().decode(errors="replace")
+        err = (SmafaPanic if pending.value == _lib.ERR_PANIC else SmafaError)(pending.value, msg)
+    try:
+        size = n.value * L.value
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(max(size, 1),))[:size].copy()
+    finally:
+        lib().smafa_free(ptr)
+    return arr.reshape(n.value, L.value), err
+
+
 def write_db(path: str, codes: np.ndarray, alphabet: int = ALPHABET_NT) -> None:
     c = np.ascontiguousarray(codes, dtype=np.uint8)
     check(lib().smafa_dbfile_write(os.fsencode(path), alphabet, c.ctypes.data, c.shape[0], c.shape[1]))

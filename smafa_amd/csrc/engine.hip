@@ -612,7 +612,7 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     // scan_wide_kernel would otherwise run (one-word stores)
     const bool zone = specialised && !seed && use_zone(db, thr0, prefilter_prunes(db, thr0));
     lazy = lazy || zone;  // (the plan reported by smafa_last_scan_plan: a filter-plane-resident kernel)
-    const uint32_t T = zone ? (uint32_t)kZoneTiles
+    const uint32_t T = zone ? (q_end - q_begin <= 64u ? (uint32_t)kFewTiles : (uint32_t)kZoneTiles)
                      : wide ? (uint32_t)kWideTiles : specialised ? tiles_per_wave(db, lazy) : (uint32_t)kGenericTiles;
     a.tile_begin = tile_begin;
     a.tile_end = tile_end;
@@ -1311,6 +1311,9 @@ int smafa_scan_launch(smafa_db *db, smafa_qset *qs, uint32_t max_div, uint32_t m
     if (max_num_hits == 0) max_num_hits = SMAFA_NONE;
     int rc = use_device(db);
     if (rc) return rc;
+    // cap = 0 with no buffer: the caller only wants the count — the kernels still need a non-NULL list to know that rows
+    // are wanted (nothing is ever written to it at capacity 0)
+    if (!d_hits) d_hits = db->ctrs.p;
     return scan_range(db, qs, 0, (uint32_t)qs->nq, max_div, max_num_hits == SMAFA_NONE ? 0u : max_num_hits,
                       (smafa_hit *)d_hits, cap, (unsigned long long *)d_count);
 }

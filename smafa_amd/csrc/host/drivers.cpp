@@ -193,6 +193,36 @@ using namespace smafa;
 extern "C" {
 
 // ---------------------------------------------------------------------------------- fastx_load
+// The records BEFORE the first offending one, and what is wrong with that one (*pending = 0 or the error code, its text in
+// smafa_last_error()): what a driver needs to print the rows the reference prints before it panics (src/lib.rs:232-318).
+int smafa_fastx_load_partial(const char *path, int alphabet, uint8_t **codes_out, uint64_t *n_out, uint32_t *seq_len,
+                             int *pending) {
+    if (!path || !codes_out || !n_out || !seq_len || !pending)
+        return set_error(SMAFA_ERR_INVALID, "smafa_fastx_load_partial: NULL argument");
+    if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
+        return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
+    *codes_out = nullptr;
+    *n_out = 0;
+    *seq_len = 0;
+    *pending = SMAFA_OK;
+    BulkRecords recs;
+    int rc = load_records_bulk(path, alphabet, false, recs);
+    if (rc) return rc;
+    uint8_t *out = (uint8_t *)malloc(recs.codes.empty() ? 1 : recs.codes.size());
+    if (!out) return set_error(SMAFA_ERR_IO, "out of memory");
+    if (!recs.codes.empty()) memcpy(out, recs.codes.data(), recs.codes.size());
+    *codes_out = out;
+    *n_out = recs.n;
+    *seq_len = (uint32_t)recs.L;
+    if (recs.err_kind == 1) *pending = set_error(SMAFA_ERR_PANIC, "%s", recs.err_msg.c_str());
+    else if (recs.err_kind == 2)
+        *pending = set_error(SMAFA_ERR_PANIC, "Cannot compute distances between seq of length %zu and windows of lengths %zu",
+                             recs.err_len, recs.L);
+    else if (recs.err_kind == 3) *pending = set_error(SMAFA_ERR_PANIC, "Cannot add empty sequence to WindowSet");
+    else if (recs.err_kind == 4) *pending = set_error(SMAFA_ERR_FORMAT, "%s", recs.err_msg.c_str());
+    return SMAFA_OK;
+}
+
 int smafa_fastx_load(const char *path, int alphabet, uint8_t **codes_out, uint64_t *n_out, uint32_t *seq_len) {
     if (!path || !codes_out || !n_out || !seq_len) return set_error(SMAFA_ERR_INVALID, "smafa_fastx_load: NULL argument");
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)

@@ -755,6 +755,10 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
 #define SMAFA_ZONE_TILES 4
 #endif
 constexpr int kZoneTiles = SMAFA_ZONE_TILES;
+#ifndef SMAFA_FEW_TILES
+#define SMAFA_FEW_TILES 4
+#endif
+constexpr int kFewTiles = SMAFA_FEW_TILES;  // wave tiles per wave in scan_zone_few_kernel
 
 // Waves per SIMD the register budget must allow.  The survivor loop is a chain of dependent slow-class instructions
 // (v_readlane -> scalar-operand xor -> bcnt -> or -> cmp -> branch), so one more resident wave pays as long as the hot
@@ -1056,7 +1060,7 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
 template <int PS, int PQ, int W>
 __global__ __launch_bounds__(256) void scan_zone_few_kernel(const uint4 *__restrict__ planes,
                                                             const uint32_t *__restrict__ qrec, ScanArgs a) {
-    constexpr int T = kZoneTiles;
+    constexpr int T = kFewTiles;
     constexpr int RS = qrec_stride(PQ, W);
     constexpr int RV = RS / 4;
     constexpr int FP = filter_plane(PQ);

@@ -146,11 +146,15 @@ def query_sharded(db_path: str, query_fasta: str, max_divergence: Optional[int] 
         import torch.distributed as dist  # type: ignore[no-redef]
     world, rank = dist.get_world_size(), dist.get_rank()
     alphabet, subj = api.read_db(db_path)
-    queries = api.load_fastx(query_fasta, alphabet)
+    # the queries in front of a bad record are answered before the failure is reported, as the reference's loop does
+    queries, pending = api.load_fastx_partial(query_fasta, alphabet)
     n, L = subj.shape
-    if len(queries) and n and queries.shape[1] != L:
+    if len(queries) and n and queries.shape[1] != L:  # the FIRST query already fails the length check: nothing is printed
         raise api.SmafaPanic(-6, "Cannot compute distances between seq of length %d and windows of lengths %d"
                              % (queries.shape[1], L))
+    if pending is not None and "seq of length" in str(pending) and n:  # a later record of another length: say the store's
+        got = str(pending).split("seq of length ")[1].split(" ")[0]
+        pending = api.SmafaPanic(-6, "Cannot compute distances between seq of length %s and windows of lengths %d" % (got, L))
     if scan_fn is None:
         scan_fn = HipScanner(alphabet, int(os.environ.get("LOCAL_RANK", rank)) if gpu is None else gpu)
     # The reference's input-independent panics (empty store, k = 0, --limit-per-sequence without k > 1;
@@ -186,6 +190,8 @@ def query_sharded(db_path: str, query_fasta: str, max_divergence: Optional[int] 
     all_rows = gather_rows(rows, dist, device)
     if rank == 0:
         api.write_rows(all_rows, subj, alphabet, out_fd)
+    if pending is not None:  # identical on every rank (same file, same loader)
+        raise pending
 
 
 def _main(argv) -> int:

@@ -43,6 +43,9 @@ def main():
                 keys = set(zip(want["query"].tolist(), want["subject"].tolist(), want["dist"].tolist()))
                 mine = list(zip(got["query"].tolist(), got["subject"].tolist(), got["dist"].tolist()))
                 assert len(set(mine)) == len(mine) == cap and set(mine) <= keys, (nq, cap)
+        store.scan_launch(qset, L, None, 0, 0, d_count.data_ptr())  # count only: no buffer at all
+        store.sync()
+        assert int(d_count.item()) == total
         # tightening mode on the same store: k = 1 keeps the rows at the minimum (the query itself and its copies)
         store.scan_launch(qset, None, 1, d_hits.data_ptr(), 1, d_count.data_ptr())
         store.sync()

@@ -87,6 +87,22 @@ def test_sharded_query_panics_on_every_rank_without_hanging(tmp_path):
     assert "Timeout" not in r.stderr and "timed out" not in r.stderr
 
 
+def test_sharded_query_prints_rows_in_front_of_a_bad_record(tmp_path):
+    """a query record with a byte outside the alphabet: the rows of the queries before it are written, then every rank
+    fails with the reference's panic text — the same bytes and exit as the oracle CLI (src/lib.rs:232-318)"""
+    db, qf = make_inputs(tmp_path, q=30)
+    raw = open(qf, "rb").read().split(b">")
+    raw[21] = raw[21][:-5] + b"E" + raw[21][-4:]  # record 20 gets a bad byte
+    open(qf, "wb").write(b">".join(raw))
+    want = oracle.run_cli("query", "-d", db, "-q", qf)
+    assert want.returncode == 101 and len(want.stdout) > 0
+    out = str(tmp_path / "out.tsv")
+    r = run_world(2, db, qf, out, [])
+    assert r.returncode != 0
+    assert open(out).read() == want.stdout
+    assert want.stderr.strip().splitlines()[-1].split("panicked")[-1][-60:] in r.stderr or "cannot be interpreted as nucleotide" in r.stderr
+
+
 @pytest.mark.gpu
 def test_sharded_query_hip_scanner_equals_oracle(tmp_path):
     """same driver, product (HIP) scanner, 2 ranks sharing GPU 0 (gloo for the row gather)"""
