@@ -93,7 +93,8 @@ def test_wide_lengths_all_modes_equal_oracle(alphabet, n_letters, L):
         assert got.tobytes() == oracle.scan_codes(s, q, D).tobytes(), (L, D)
         plan = store.last_scan_plan()
         # W = 3, 4 keep the per-length kernels (8 subjects per lane); SMAFA_WIDE_FROM=3 moves them
-        if os.environ.get("SMAFA_FILTER", "1") == "0" or os.environ.get("SMAFA_LAZY", "1") == "0":
+        if (os.environ.get("SMAFA_FILTER", "1") == "0" or os.environ.get("SMAFA_LAZY", "1") == "0"
+                or os.environ.get("SMAFA_ZONE", "1") == "2"):
             continue  # forced kernel forms: rows only
         moved = int(os.environ.get("SMAFA_WIDE_FROM", "5")) <= 3
         assert plan["filter_plane_resident"] == (D < 8)
