@@ -208,7 +208,8 @@ void smafa_free(void *p);
 /* makedb(subject_fasta, db_path) — src/lib.rs:137-165.  Host only (no GPU needed). */
 int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet);
 /* makedb with the packed store file as output: the subjects are packed on `device` (the layout is the one a query
- * would build) and saved with smafa_db_save.  Needs a GPU; plain smafa_makedb does not. */
+ * would build) and saved with smafa_db_save.  device < 0, or no GPU visible: packed by host threads instead — the same
+ * bytes (host/layout.cpp restates the device's packing; the two files are compared in tests/test_gpu_layout.py). */
 int smafa_makedb_packed(const char *subject_fasta, const char *db_path, int alphabet, int device);
 /* query(db_path, query_fasta, max_divergence, max_num_hits, limit_per_sequence) — src/lib.rs:198-325.
  * Options use SMAFA_NONE for None.  TSV rows go to out_fd (the reference prints to stdout). */

@@ -277,7 +277,7 @@ def makedb(subject_fasta: str, db_path: str, alphabet: int = ALPHABET_NT) -> Non
 
 
 def makedb_packed(subject_fasta: str, db_path: str, alphabet: int = ALPHABET_NT, device: int = 0) -> None:
-    """makedb writing the packed store file (needs a GPU: the subjects are packed on `device`)."""
+    """makedb writing the packed store file; packed on GPU `device`, or by host threads when device < 0 or there is no GPU."""
     check(lib().smafa_makedb_packed(os.fsencode(subject_fasta), os.fsencode(db_path), alphabet, device))
 
 

@@ -142,79 +142,9 @@ static int use_device(const smafa_db *db) {
 //     2-plane form of an N-free store holds bits 0 and 1); of the three A/C/G/T pairings, {A,C}|{G,T} is preferred
 //     while it is within 5 % of the best — it is the one that sees transitions, the commonest real substitutions.
 //   * columns are ordered by that flip probability, 2p(1-p), best first: conserved columns end up in the last words.
-// Decided once per handle, from a sample of the first rows it receives.
+// Decided once per handle, from a sample of the first rows it receives (compute_layout, host/layout.cpp).
 static int choose_layout(smafa_db *db, const uint8_t *codes, uint64_t n) {
-    const uint32_t L = db->L;
-    const bool aa = db->alphabet == SMAFA_ALPHABET_AA;
-    const uint32_t n_sym = aa ? 28u : 4u, side_cap = aa ? 16u : 2u;
-    std::vector<uint32_t> cnt((size_t)L * 32, 0);
-    // SMAFA_LAYOUT=0 (A/B runs, tools/layout_check.py): no statistics — columns in file order, the default code split
-    const char *lv = getenv("SMAFA_LAYOUT");
-    const uint64_t S = (lv && atoi(lv) == 0) ? 0 : std::min<uint64_t>(n, 4096);
-    for (uint64_t k = 0; k < S; k++) {
-        const uint8_t *row = codes + (size_t)(k * n / S) * L;
-        for (uint32_t c = 0; c < L; c++) cnt[(size_t)c * 32 + (row[c] & 31u)]++;
-    }
-    db->tab.assign((size_t)L * 32, 0);
-    std::vector<double> score(L, 0.0);
-    for (uint32_t c = 0; c < L; c++) {
-        const uint32_t *cc = &cnt[(size_t)c * 32];
-        uint8_t *tc = &db->tab[(size_t)c * 32];
-        for (uint32_t v = 0; v < 32; v++) tc[v] = (uint8_t)v;  // codes outside the movable set keep their value
-        uint32_t side_of[32];
-        uint64_t tot[2] = {0, 0};
-        auto balance = [&]() {
-            const double all = (double)(tot[0] + tot[1]);
-            return all > 0 ? 2.0 * (double)tot[0] * (double)tot[1] / (all * all) : 0.0;
-        };
-        if (!aa) {
-            // three pairings of A C G T (codes 0..3); side 1 listed
-            static const uint8_t pair[3][2] = {{2, 3}, {1, 3}, {1, 2}};  // {A,C}|{G,T}  {A,G}|{C,T}  {A,T}|{C,G}
-            double sc[3];
-            for (int k = 0; k < 3; k++) {
-                tot[1] = (uint64_t)cc[pair[k][0]] + cc[pair[k][1]];
-                tot[0] = (uint64_t)cc[0] + cc[1] + cc[2] + cc[3] - tot[1];
-                sc[k] = balance();
-            }
-            int best = 0;
-            const double top = std::max(sc[0], std::max(sc[1], sc[2]));
-            if (sc[0] < 0.95 * top) best = sc[1] >= sc[2] ? 1 : 2;
-            for (uint32_t v = 0; v < 4; v++) side_of[v] = (v == pair[best][0] || v == pair[best][1]) ? 1u : 0u;
-            score[c] = sc[best];
-        } else {
-            uint32_t idx[32], num[2] = {0, 0};
-            for (uint32_t v = 0; v < n_sym; v++) idx[v] = v;
-            std::stable_sort(idx, idx + n_sym, [&](uint32_t x, uint32_t y) { return cc[x] > cc[y]; });
-            for (uint32_t k = 0; k < n_sym; k++) {
-                uint32_t side = tot[0] <= tot[1] ? 0u : 1u;
-                if (num[side] == side_cap) side ^= 1u;
-                side_of[idx[k]] = side;
-                tot[side] += cc[idx[k]];
-                num[side]++;
-            }
-            score[c] = balance();
-        }
-        uint32_t next[2] = {0, 1};  // even codes for side 0, odd for side 1, in code order
-        bool used[32] = {false};
-        for (uint32_t v = 0; v < n_sym; v++) {
-            tc[v] = (uint8_t)next[side_of[v]];
-            used[next[side_of[v]]] = true;
-            next[side_of[v]] += 2;
-        }
-        if (aa) {  // codes 28..31 never occur; keep the map a permutation anyway
-            uint32_t free_v = 0;
-            for (uint32_t v = n_sym; v < 32; v++) {
-                while (used[free_v]) free_v++;
-                tc[v] = (uint8_t)free_v;
-                used[free_v] = true;
-            }
-        }
-    }
-    std::vector<uint32_t> cols(L);
-    for (uint32_t c = 0; c < L; c++) cols[c] = c;
-    std::stable_sort(cols.begin(), cols.end(), [&](uint32_t x, uint32_t y) { return score[x] > score[y]; });
-    db->perm.assign((size_t)db->W * 32, 0);
-    for (uint32_t j = 0; j < L; j++) db->perm[j] = (uint16_t)cols[j];
+    compute_layout(db->alphabet, db->L, codes, n, db->perm, db->tab);  // host/layout.cpp
     int rc = db->d_perm.ensure(db->perm.size() * sizeof(uint16_t));
     if (!rc) rc = db->d_tab.ensure(db->tab.size());
     if (rc) return rc;

@@ -280,7 +280,7 @@ int smafa_makedb_packed(const char *subject_fasta, const char *db_path, int alph
     if (!subject_fasta || !db_path) return set_error(SMAFA_ERR_INVALID, "smafa_makedb_packed: NULL path");
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
-    std::thread warm(warm_device, device);
+    std::thread warm(warm_device, device < 0 ? 1 << 30 : device);  // (an out-of-range device: nothing to warm)
     BulkRecords recs;
     int rc = load_records_bulk(subject_fasta, alphabet, false, recs);  // src/lib.rs:143-152
     warm.join();
@@ -292,6 +292,12 @@ int smafa_makedb_packed(const char *subject_fasta, const char *db_path, int alph
     if (recs.err_kind == 4) return set_error(SMAFA_ERR_FORMAT, "%s", recs.err_msg.c_str());
     if (recs.n == 0) return set_error(SMAFA_ERR_INVALID, "a packed store needs at least one sequence (its length fixes the layout)");
     if (recs.L > 0xffffffffull) return set_error(SMAFA_ERR_INVALID, "sequence too long");
+    if (device < 0 || smafa_device_count() == 0) {  // no GPU (or none wanted): the same file, packed by host threads
+        log_line(1, "Encoding of %llu sequences complete, packing on the host and writing %s", (unsigned long long)recs.n, db_path);
+        rc = pack_store_on_host(alphabet, (uint32_t)recs.L, recs.codes.data(), recs.n, db_path);
+        if (rc == SMAFA_OK) log_line(1, "DB file written");
+        return rc;
+    }
     log_line(1, "Encoding of %llu sequences complete, packing on device %d and writing %s", (unsigned long long)recs.n, device, db_path);
     DbGuard guard;
     rc = smafa_db_create(&guard.db, device, alphabet, (uint32_t)recs.L);

@@ -30,7 +30,8 @@ static int usage(const char *msg) {
             "  cluster  Cluster sequences by similarity\n"
             "  count    Print the number of reads/bases in a possibly gzipped FASTX file\n\n"
             "makedb  -i, --input <FILE>  -d, --database <FILE>  [--alphabet nt|aa] [--packed [--device <N>]]\n"
-            "        --packed: write the store as it lies in GPU memory (needs a GPU; loads without decoding)\n"
+            "        --packed: write the store as it lies in GPU memory (loads without decoding); packed on the GPU, or by\n"
+            "        host threads when there is none or with --no-gpu (the same bytes)\n"
             "query   -d, --database <FILE>  -q, --query <FILE>  [--max-divergence <INT>] [--max-num-hits <INT>]\n"
             "        [--limit-per-sequence <INT>] [--device <N> | --gpus <N> | --devices <a,b,..>]\n"
             "        Output columns (tab-separated): query number (0-indexed), subject number (0-indexed),\n"
@@ -60,7 +61,7 @@ int main(int argc, char **argv) {
     const char *input = nullptr, *database = nullptr, *query = nullptr;
     std::vector<const char *> count_paths;
     uint32_t max_div = SMAFA_NONE, max_hits = SMAFA_NONE, limit = SMAFA_NONE, device = 0;
-    bool have_max_div = false, packed = false;
+    bool have_max_div = false, packed = false, no_gpu = false;
     std::vector<int> devices;  // query: more than one handle
     int alphabet = SMAFA_ALPHABET_NT;
     int verbosity = 1;  // the reference logs at info level unless told otherwise (bird_tool_utils set_log_level)
@@ -93,6 +94,8 @@ int main(int argc, char **argv) {
             if (!parse_u32(value(), &device)) return usage("--device needs an unsigned integer");
         } else if (a == "--packed") {
             packed = true;
+        } else if (a == "--no-gpu") {
+            no_gpu = true;
         } else if (a == "--gpus") {
             uint32_t g = 0;
             if (!parse_u32(value(), &g) || g < 1 || g > 64) return usage("--gpus needs a count between 1 and 64");
@@ -134,7 +137,7 @@ int main(int argc, char **argv) {
     int rc;
     if (cmd == "makedb") {
         if (!input || !database) return usage("makedb needs --input and --database");
-        rc = packed ? smafa_makedb_packed(input, database, alphabet, (int)device) : smafa_makedb(input, database, alphabet);
+        rc = packed ? smafa_makedb_packed(input, database, alphabet, no_gpu ? -1 : (int)device) : smafa_makedb(input, database, alphabet);
     } else if (cmd == "query") {
         if (!database || !query) return usage("query needs --database and --query");
         if (devices.empty()) devices.push_back((int)device);

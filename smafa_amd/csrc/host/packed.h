@@ -39,6 +39,12 @@ class PackedStore {
     std::vector<uint8_t> untab;  // [source column][stored code] -> code, 255 = never produced
 };
 
+// column order + per-column code table of a store, from a sample of its rows (host/layout.cpp)
+void compute_layout(int alphabet, uint32_t L, const uint8_t *codes, uint64_t n, std::vector<uint16_t> &perm,
+                    std::vector<uint8_t> &tab);
+// the packed store file of n code rows, packed on the host (no GPU): the same bytes smafa_db_save writes for them
+int pack_store_on_host(int alphabet, uint32_t L, const uint8_t *codes, uint64_t n, const char *path);
+
 int write_packed_file(const char *path, const PackedHeader &hdr, const uint16_t *perm, const uint8_t *tab,
                       const uint64_t *runs, const uint32_t *order, const void *zone, const uint32_t *planes);
 

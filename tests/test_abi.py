@@ -374,3 +374,47 @@ def test_db_with_a_non_one_hot_group_is_rejected_at_load(golden, tmp_path):
     open(p, "wb").write(empty)
     with pytest.raises(smafa_amd.SmafaError):
         smafa_amd.read_db(p)
+
+
+@pytest.mark.parametrize("alphabet,n_letters,n", [(0, 4, 3000), (0, 5, 6000), (1, 24, 9000)])
+def test_packed_store_file_written_without_a_gpu(tmp_path, alphabet, n_letters, n):
+    """`smafa makedb --packed --no-gpu`: the packed store file from host threads (host/layout.cpp).  It decodes back to the
+    code rows, the reference-side version gate rejects it with its own text, and damaged copies are refused at open time."""
+    import struct
+
+    rng = np.random.default_rng(n)
+    L = 60
+    s = rng.integers(0, n_letters, size=(n, L), dtype=np.uint8)
+    s[:, :20] = np.where(rng.random((n, 20)) < 0.9, s[0, :20], s[:, :20])  # conserved columns: the layout reorders them
+    from smafa_amd import synth
+    fa, pk = str(tmp_path / "s.fa"), str(tmp_path / "s.packed")
+    synth.write_fasta(fa, s, alphabet)
+    r = cli("makedb", "-i", fa, "-d", pk, "--packed", "--no-gpu", *(["--alphabet", "aa"] if alphabet else []))
+    assert r.returncode == 0, r.stderr
+    good = open(pk, "rb").read()
+    assert good[:8] == b"\x03\x02SMAFA\x00"
+    a, codes = smafa_amd.read_db(pk)
+    assert a == alphabet and codes.tobytes() == s.tobytes()
+    planes = struct.unpack_from("<I", good, 8 + 8)[0]
+    assert planes == (5 if alphabet else (3 if n_letters == 5 else 2))
+    ref = oracle.run_cli("query", "-d", pk, "-q", fa)  # src/lib.rs:214-217
+    assert ref.returncode != 0 and "Unsupported db file version: 3." in ref.stderr
+
+    def damaged(edit, name):
+        b = bytearray(good)
+        edit(b)
+        p = str(tmp_path / name)
+        open(p, "wb").write(bytes(b))
+        return p
+
+    cases = {
+        "trunc": lambda b: b.__delitem__(slice(len(b) - 4096, len(b))),
+        "rows": lambda b: b.__setitem__(slice(8 + 16, 8 + 24), struct.pack("<Q", 10**9)),
+        "planes": lambda b: b.__setitem__(slice(8 + 8, 8 + 12), struct.pack("<I", 7)),
+        "perm": lambda b: b.__setitem__(slice(4096, 4098), struct.pack("<H", 60)),
+        "tab": lambda b: b.__setitem__(slice(8192, 8194), b"\x00\x00"),
+        "offset": lambda b: b.__setitem__(slice(8 + 40 + 48, 8 + 40 + 56), struct.pack("<Q", len(good))),
+    }
+    for name, edit in cases.items():
+        with pytest.raises(smafa_amd.SmafaError):
+            smafa_amd.read_db(damaged(edit, name))

@@ -355,3 +355,26 @@ def test_packed_store_rejects_damaged_files(tmp_path):
         with pytest.raises(smafa_amd.SmafaError):
             smafa_amd.read_db(damaged(edit, name))
     smafa_amd.SubjectStore.load(damaged(lambda b: None, "same")).close()
+
+
+@pytest.mark.parametrize("alphabet,n_letters,n", [(0, 4, 3000), (0, 4, 30000), (0, 5, 12000), (1, 20, 30000), (1, 28, 5000)])
+def test_host_packed_file_equals_device_saved_file(tmp_path, alphabet, n_letters, n):
+    """the host restatement of the device's packing (layout, stable sort by filter words, ballot bit-planes, order, zone
+    words) must produce the SAME BYTES as smafa_db_save of a store packed by the kernels — an independent check of
+    pack_rows_kernel, row_keys_kernel, the radix sort's stability and zone_kernel"""
+    from smafa_amd import synth
+
+    rng = np.random.default_rng(n + n_letters)
+    s = skewed_store(rng, n, 60, n_letters, families=30)
+    fa = str(tmp_path / "s.fa")
+    synth.write_fasta(fa, s, alphabet)
+    host, dev = str(tmp_path / "host.packed"), str(tmp_path / "dev.packed")
+    smafa_amd.makedb_packed(fa, host, alphabet, device=-1)
+    smafa_amd.makedb_packed(fa, dev, alphabet, device=0)
+    a, b = open(host, "rb").read(), open(dev, "rb").read()
+    assert len(a) == len(b)
+    assert a == b
+    q = queries_from(rng, s, 64, n_letters, 6)
+    store = smafa_amd.SubjectStore.load(host)
+    assert store.scan(q, max_divergence=5).tobytes() == oracle.scan_codes(s, q, 5).tobytes()
+    store.close()

@@ -10,7 +10,7 @@ OUT=${OUT:-/tmp/asan}
 mkdir -p "$OUT"
 make -C "$ROOT/smafa_amd/csrc" -j8 >/dev/null
 cd "$ROOT/smafa_amd/csrc"
-for f in common alphabet fastx dbfile select packed drivers; do
+for f in common alphabet fastx dbfile select packed layout drivers; do
   g++ -O1 -g -std=c++17 -fPIC -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -c host/$f.cpp -o "$OUT/$f.o"
 done
 g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined -c host/main.cpp -o "$OUT/main.o"
@@ -45,6 +45,16 @@ synth.write_fasta(out + "/small.fna", synth.subjects(300, 70, 0, seed=3, n_frac=
 run("makedb", "-i", out + "/big.fna", "-d", out + "/big.db"); run("query", "-d", out + "/big.db", "-q", out + "/small.fna")
 run("cluster", "-i", out + "/big.fna", "-d", "3"); run("count", "-i", out + "/big.fna")
 run("makedb", "-i", out + "/small.fna", "-d", out + "/small.db")
+# the packed store file written on the host, then read back (query decodes it up to the point where it needs a device)
+run("makedb", "-i", out + "/big.fna", "-d", out + "/big.packed", "--packed", "--no-gpu")
+run("makedb", "-i", out + "/small.fna", "-d", out + "/small.packed", "--packed", "--no-gpu")
+run("query", "-d", out + "/small.packed", "-q", out + "/small.fna")
+pk = open(out + "/small.packed", "rb").read()
+for _ in range(150):
+    d = bytearray(pk)
+    for _ in range(rng.randint(1, 5)): d[rng.randrange(len(d))] = rng.randrange(256)
+    open(out + "/m.packed", "wb").write(bytes(d[: rng.randrange(8, len(d))] if rng.random() < 0.3 else d))
+    run("query", "-d", out + "/m.packed", "-q", out + "/small.fna")
 # the threaded FASTQ / gzip loaders (>= 32 MB after decompression), whole and truncated
 import gzip
 rows = synth.subjects(560_000, 60, 0, seed=4, n_frac=0.001)
