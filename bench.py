@@ -99,27 +99,16 @@ def cpu_model() -> str:
     return "unknown"
 
 
-_B2 = {}  # state the forked B2 workers inherit
-
-
-def _b2_work(idx):
-    import numpy as np
-
-    return _B2["db"].bench_besthit(np.ascontiguousarray(_B2["enc"][idx]), _B2["D"])
-
-
 def cpu_baselines(N, L, D, alphabet_name, subj_codes, q_codes, budget_s):
     """SURVEY 8(d) / BASELINE.md §2: the reference's per-query loop (src/lib.rs:238 distances, :298 min, :307 equality
     pass) restated by the oracle and timed on this host, each on a bounded sample.
       B1   5-bit one-hot u64 x ceil(L/12) per subject (the reference's own arithmetic, src/lib.rs:71-89), ONE thread,
            gcc -O3 for baseline x86-64 (no POPCNT: what `cargo build --release` gives)
       B1n  the same, -march=native
-      B2   B1n over min(16, nproc) worker processes (query shards; the reference has no threads: a courtesy baseline)
+      B2   B1n over min(16, nproc) worker threads (query shards; the reference has no threads: a courtesy baseline)
       aa   the code-byte port (one byte per column): the only CPU form that can hold amino-acid letters
     The reference's cost does not depend on the letters (same words per subject), so for the amino-acid metric B1..B2
     run on a nucleotide store of the same shape (seed 2) — the reference itself rejects amino-acid input."""
-    import multiprocessing as mp
-
     import numpy as np
 
     import oracle
@@ -152,18 +141,26 @@ def cpu_baselines(N, L, D, alphabet_name, subj_codes, q_codes, budget_s):
         if native:
             workers = min(16, os.cpu_count() or 1)
             per_q = dt / n_s
-            n_b2 = int(max(workers, min(len(enc), workers * budget_s / per_q)))
+            n_b2 = int(max(workers, min(len(enc), workers * 0.25 * budget_s / per_q)))  # a pass = a quarter of the budget
             shards = np.array_split(np.arange(n_b2), workers)
 
-            _B2.update(db=db, enc=enc, D=D)
-            ctx = mp.get_context("fork")  # the store is shared copy-on-write with the workers
-            t = time.perf_counter()
-            with ctx.Pool(workers) as pool:
-                pool.map(_b2_work, shards)
-            dt2 = time.perf_counter() - t
-            _B2.clear()
+            # worker THREADS: the oracle's C loop runs without the interpreter lock (ctypes releases it) and allocates its
+            # distance buffer per call; no process is forked from one that has initialised the GPU
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(workers) as pool:
+                run = lambda idx: db.bench_besthit(np.ascontiguousarray(enc[idx]), D)
+                # the first second or two of a threaded burst can run far below the steady rate (CPU wake-up / scheduler
+                # quota): passes over the same shards until the budget is used, the fastest pass is reported
+                dt2, t_all = float("inf"), time.perf_counter()
+                while True:
+                    t = time.perf_counter()
+                    list(pool.map(run, shards))
+                    dt2 = min(dt2, time.perf_counter() - t)
+                    if time.perf_counter() - t_all > budget_s:
+                        break
             out["b2"] = {"value": n_b2 / dt2, "unit": "query seqs/s", "cores": workers, "queries": n_b2,
-                         "build": "gcc -O3 -march=native, %d worker processes" % workers}
+                         "build": "gcc -O3 -march=native, %d worker threads, fastest pass of the budget" % workers}
         db.close()
     if alphabet_name == "aa":
         t = time.perf_counter()
