@@ -781,6 +781,7 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
     constexpr int BS = bound_slot(W);
     constexpr bool kPair = SMAFA_AND_PAIR && W > 1;
     __shared__ uint4 stage[2][kChunk * RV];
+    __shared__ uint32_t nu_lds[2][kChunk];  // !FIXED: ~bound of the staged queries
     __shared__ RowStage rs;
     int buf = 0;  // LDS buffer of the chunk being computed = parity of the row stage it appends to
 
@@ -819,35 +820,11 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
     }
     const bool zone_w1 = W > 1 && __ballot(vz.w != 0u) != 0ull;
 
-    uint4 pre[NV];
-    auto fetch = [&](uint32_t qc) {
-        const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
-        const uint4 *src = reinterpret_cast<const uint4 *>(qrec + (size_t)qc * RS);
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-            const uint32_t idx = tid + v * 256;
-            if (idx < nqc * RV) {
-                uint4 x = src[idx];
-                if (idx % RV == BS / 4) {
-                    const uint32_t nu = ~(a.thr ? ld_relaxed(a.thr + qc + idx / RV) : a.thr0);
-                    if ((BS & 3) == 0) x.x = nu;
-                    else if ((BS & 3) == 1) x.y = nu;
-                    else if ((BS & 3) == 2) x.z = nu;
-                    else x.w = nu;
-                }
-                pre[v] = x;
-            }
-        }
-    };
-    auto commit = [&](int b, uint32_t qc) {
-        const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-            const uint32_t idx = tid + v * 256;
-            if (idx < nqc * RV) stage[b][idx] = pre[v];
-        }
-    };
-    auto dma = [&](int b, uint32_t qc) {  // FIXED: global -> LDS directly; lands at wave base + lane * 16 (lane-linear)
+    // Query chunks are staged by LDS-DMA (global_load_lds_dwordx4: global -> LDS with no register hop; a register
+    // prefetch was being spilled across every chunk).  The records carry no bound in this kernel: FIXED takes the scalar
+    // ~thr0, !FIXED keeps the chunk's per-query ~bound in nu_lds (read from thr at the top of the previous chunk, one
+    // register per thread in flight, written at its end).
+    auto dma = [&](int b, uint32_t qc) {  // lands at wave base + lane * 16 (lane-linear)
         const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
         const uint4 *src = reinterpret_cast<const uint4 *>(qrec + (size_t)qc * RS);
 #pragma unroll
@@ -859,6 +836,10 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
         }
     };
     const uint32_t nu0 = ~a.thr0;  // FIXED: every query's ~bound
+    auto load_bound = [&](uint32_t qc) -> uint32_t {  // !FIXED: this thread's query of the chunk at qc
+        return tid < min((uint32_t)kChunk, q1 - qc) ? ~ld_relaxed(a.thr + qc + tid) : 0u;
+    };
+    uint32_t nu_next = 0;
     auto read_record = [&](const uint4 *rec, uint32_t(&qw)[RS]) {
 #pragma unroll
         for (int v = 0; v < RV; v++) {
@@ -902,12 +883,8 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
     };
 
     if (q0 < q1) {
-        if (FIXED) {
-            dma(0, q0);
-        } else {
-            fetch(q0);
-            commit(0, q0);
-        }
+        dma(0, q0);
+        if (!FIXED && tid < (uint32_t)kChunk) nu_lds[0][tid] = load_bound(q0);
     }
     __syncthreads();  // (drains the DMA: its fence waits for vmcnt(0))
     bool filter_on = a.use_filter != 0;
@@ -916,8 +893,8 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
         const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
         const bool more = qc + kChunk < q1;
         if (more) {  // in flight while this chunk is computed
-            if (FIXED) dma(buf ^ 1, qc + kChunk);  // every wave passed the barrier that ended the last use of that buffer
-            else fetch(qc + kChunk);
+            dma(buf ^ 1, qc + kChunk);  // every wave passed the barrier that ended the last use of that buffer
+            if (!FIXED) nu_next = load_bound(qc + kChunk);
         }
         if (active) {
             const bool probe = a.use_filter && (filter_on || (chunk_no & 15u) == 0);
@@ -927,7 +904,7 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
                 uint4 head = make_uint4(0u, 0u, 0u, 0u);  // lanes past the chunk: ~bound = 0 never passes
                 if (lane < nqc) head = stage[buf][lane * RV];
                 const uint32_t hq0 = head.x, hq1 = W > 1 ? head.y : 0u;
-                const uint32_t hnu = FIXED ? (lane < nqc ? nu0 : 0u) : (BS == 1 ? head.y : head.z);
+                const uint32_t hnu = lane < nqc ? (FIXED ? nu0 : nu_lds[buf][lane]) : 0u;
                 // Tile by tile, unrolled (the rare levels' address math stays inside their branch thanks to the opaque
                 // tile number below; a run-time tile loop cost 4 % on aa and 27 % on nt at bound 3 in per-tile
                 // bookkeeping — profiles/r02_zone_variants.txt).
@@ -969,7 +946,7 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
                         // ---- level 2 (rare): the filter plane folded over all its words, words 1.. from L2/HBM
                         uint32_t qw[RS];
                         read_record(&stage[buf][(uint32_t)i * RV], qw);
-                        if (FIXED) qw[BS] = nu0;  // the staged record carries no bound in this form
+                        qw[BS] = nu;  // the staged record carries no bound
                         uint32_t m0 = ft.x ^ qw[0], m1 = ft.y ^ qw[0], m2 = ft.z ^ qw[0], m3 = ft.w ^ qw[0];
                         if (W > 1) {
                             const uint4 *src = planes + (size_t)tile_r * (PS * W * 64) + (FP * W) * 64 + lane;
@@ -1011,7 +988,7 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
                     for (uint32_t i = 0; i < nqc; i++, rec += RV) {
                         uint32_t qw[RS];
                         read_record(rec, qw);
-                        const uint32_t U = FIXED ? a.thr0 : ~qw[BS];
+                        const uint32_t U = FIXED ? a.thr0 : ~nu_lds[buf][i];
                         uint32_t d[4];
 #pragma unroll
                         for (int w = 0; w < W; w++) {
@@ -1042,8 +1019,8 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
                 load_filter();  // not kept across the walk (its registers hold the tile meanwhile): fetched again
             }
         }
-        if (more && !FIXED) commit(buf ^ 1, qc + kChunk);
-        __syncthreads();  // FIXED: also where the next chunk's DMA is waited for (vmcnt(0) in the barrier's fence)
+        if (more && !FIXED && tid < (uint32_t)kChunk) nu_lds[buf ^ 1][tid] = nu_next;
+        __syncthreads();  // also where the next chunk's DMA is waited for (vmcnt(0) in the barrier's fence)
         if (a.hits) flush_rows(a, rs, buf);
     }
     finish_rows(a);
