@@ -195,7 +195,8 @@ static int pack_rows(smafa_db *db, const uint8_t *codes, uint64_t first, uint64_
     uint8_t *d_codes = db->upload.as<uint8_t>();
     HIP_TRY(hipMemcpyAsync(d_codes, codes, bytes, hipMemcpyHostToDevice, db->stream));
     const uint32_t *d_src = nullptr;
-    const bool sorted = mode == 0 && db->sort_rows && n >= kSortMin;
+    // (the device radix sort counts its items in an int: appends of 2^31 rows and more keep their order)
+    const bool sorted = mode == 0 && db->sort_rows && n >= kSortMin && n < (1ull << 31);
     if (sorted) {
         rc = db->keys_a.ensure(n * sizeof(unsigned long long));
         if (!rc) rc = db->keys_b.ensure(n * sizeof(unsigned long long));

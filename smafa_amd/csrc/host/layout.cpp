@@ -136,7 +136,7 @@ int pack_store_on_host(int alphabet, uint32_t L, const uint8_t *codes, uint64_t 
     std::vector<uint8_t> tab;
     compute_layout(alphabet, L, codes, n, perm, tab);
     // ---- sort key per row (row_keys_kernel), stable sort (the device's radix sort is stable)
-    const bool sorted = n >= 4096;  // kSortMin of engine.hip
+    const bool sorted = n >= 4096 && n < (1ull << 31);  // kSortMin and the sort limit of engine.hip
     std::vector<uint32_t> src(n);
     for (uint64_t i = 0; i < n; i++) src[i] = (uint32_t)i;
     if (sorted) {
