@@ -106,6 +106,10 @@ struct smafa_db {
     // more, many small appends share few — use_zone() works from this, not from assumptions about the data.
     std::vector<uint8_t> tile_bits;
     uint64_t zone_hist[65] = {0};
+    uint64_t rows_since_sort = 0;  // rows appended since the whole store was last in one sorted run
+    uint32_t resorts = 0;          // full re-sorts so far (resort_store)
+    bool resort = true;            // SMAFA_RESORT=0: never
+    uint64_t resort_min = 32768;   // stores below this many rows are left alone (SMAFA_RESORT_MIN)
     double zone_loose = 0.3;      // pass share below which the zone kernel also takes bounds level 1 cannot prune at (SMAFA_ZONE_LOOSE)
     int zone = 1;                 // zone level of the filter-plane-resident kernel: 1 = where it prunes (use_zone), 0 = never
                                   // (SMAFA_ZONE=0), 2 = whenever that kernel runs (SMAFA_ZONE=2, tests)
@@ -223,7 +227,7 @@ static int pack_rows(smafa_db *db, const uint8_t *codes, uint64_t first, uint64_
     if (mode == 0) {
         const uint32_t t0 = (uint32_t)(first / kWaveTile), t1 = (uint32_t)((first + n + kWaveTile - 1) / kWaveTile);
         hipLaunchKernelGGL(zone_kernel, dim3((t1 - t0 + kWgWaves - 1) / kWgWaves), dim3(256), 0, db->stream,
-                           reinterpret_cast<const uint4 *>(db->d_planes), db->P, db->W, t0, t1, (uint32_t)(first + n), db->d_zone);
+                           reinterpret_cast<const uint4 *>(db->d_planes), db->P, db->W, db->L, t0, t1, (uint32_t)(first + n), db->d_zone);
         HIP_TRY(hipGetLastError());
         db->runs.push_back({n, sorted});
         std::vector<uint4> z(t1 - t0);
@@ -234,6 +238,85 @@ static int pack_rows(smafa_db *db, const uint8_t *codes, uint64_t first, uint64_
     // the caller's host buffer is borrowed for the call only, and `upload` is reused by the next call
     HIP_TRY(hipStreamSynchronize(db->stream));
     return SMAFA_OK;
+}
+
+// A store that grew by many appends — a DB loaded in pieces, cluster's centroid set — is a patchwork of runs that were
+// sorted one by one (or not at all, below kSortMin rows): its tiles share far fewer filter bits than a store of that size
+// can.  Before a scan, once the rows appended since the last full sort make up a quarter of the store, the whole store is
+// sorted again ON THE DEVICE: keys read back from the filter plane, one radix sort, every row moved to its new position
+// (planes and order[]), zone words recomputed.  Each re-sort is paid for by the growth since the last one (geometric:
+// <= 4 row moves per row over the store's life); subject indices (order[]) do not change, only positions do.
+// No room for a second copy of the planes: the store stays as it is.
+static int resort_store(smafa_db *db) {
+    const uint64_t n = db->n;
+    const double t_begin = now_seconds();
+    db->rows_since_sort = 0;  // whatever happens below: not again before the store has grown
+    int rc = db->keys_a.ensure(n * sizeof(unsigned long long));
+    if (!rc) rc = db->keys_b.ensure(n * sizeof(unsigned long long));
+    if (!rc) rc = db->idx_a.ensure(n * sizeof(uint32_t));
+    if (!rc) rc = db->idx_b.ensure(n * sizeof(uint32_t));
+    if (rc) return rc;
+    uint32_t *d_new = nullptr, *d_order = nullptr;
+    const size_t bytes = db->cap_tiles * db->tile_words() * sizeof(uint32_t);
+    const size_t order_bytes = db->cap_tiles * kWaveTile * sizeof(uint32_t);
+    if (hipMalloc(&d_new, bytes) != hipSuccess || hipMalloc(&d_order, order_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (d_new) (void)hipFree(d_new);
+        return SMAFA_OK;
+    }
+    auto fail = [&](int code) {
+        (void)hipFree(d_new);
+        (void)hipFree(d_order);
+        return code;
+    };
+    unsigned long long *ka = db->keys_a.as<unsigned long long>(), *kb = db->keys_b.as<unsigned long long>();
+    uint32_t *ia = db->idx_a.as<uint32_t>(), *ib = db->idx_b.as<uint32_t>();
+    const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    hipError_t e = hipMemsetAsync(d_new, 0, bytes, db->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_order, 0, order_bytes, db->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(position_keys_kernel, dim3(blocks), dim3(256), 0, db->stream, db->d_planes, db->P, db->W, n, ka, ia);
+        e = hipGetLastError();
+    }
+    size_t tmp_bytes = 0;
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ka, kb, ia, ib, (int)n, 0, 64, db->stream);
+    if (e == hipSuccess && (rc = db->sort_tmp.ensure(tmp_bytes)) != 0) return fail(rc);
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(db->sort_tmp.p, tmp_bytes, ka, kb, ia, ib, (int)n, 0, 64, db->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(permute_rows_kernel, dim3(blocks), dim3(256), 0, db->stream, db->d_planes, d_new, ib, db->d_order,
+                           d_order, n, db->P * db->W);
+        e = hipGetLastError();
+    }
+    const uint32_t n_tiles = (uint32_t)((n + kWaveTile - 1) / kWaveTile);
+    std::vector<uint4> z(n_tiles);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(zone_kernel, dim3((n_tiles + kWgWaves - 1) / kWgWaves), dim3(256), 0, db->stream,
+                           reinterpret_cast<const uint4 *>(d_new), db->P, db->W, db->L, 0u, n_tiles, (uint32_t)n, db->d_zone);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(z.data(), db->d_zone, z.size() * sizeof(uint4), hipMemcpyDeviceToHost, db->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
+    if (e != hipSuccess) return fail(set_error(SMAFA_ERR_DEVICE, "re-sorting the store failed: %s", hipGetErrorString(e)));
+    (void)hipFree(db->d_planes);
+    (void)hipFree(db->d_order);
+    db->d_planes = d_new;
+    db->d_order = d_order;
+    db->tile_bits.clear();
+    for (uint64_t &h : db->zone_hist) h = 0;
+    note_zone_words(db, 0, z.data(), z.size());
+    db->runs.assign(1, {n, true});
+    db->resorts++;
+    log_line(2, "store of %llu rows sorted again on the device in %.2f ms (re-sort %u)", (unsigned long long)n,
+             (now_seconds() - t_begin) * 1e3, db->resorts);
+    if (n > (1u << 20))
+        for (DevBuf *b : {&db->keys_a, &db->keys_b, &db->idx_a, &db->idx_b, &db->sort_tmp}) b->release();
+    return SMAFA_OK;
+}
+
+static int maybe_resort(smafa_db *db) {
+    if (!db->sort_rows || !db->resort || db->runs.size() < 2 || db->n < db->resort_min || db->n >= (1ull << 31)) return SMAFA_OK;
+    if (db->rows_since_sort * 4 < db->n) return SMAFA_OK;
+    return resort_store(db);
 }
 
 static int validate_codes(const smafa_db *db, const uint8_t *codes, uint64_t n, uint8_t *max_code = nullptr) {
@@ -597,6 +680,8 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
         HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), db->stream));
         return SMAFA_OK;
     }
+    int prc = maybe_resort(db);
+    if (prc) return prc;
     unsigned long long *d_ctr = db->ctrs.as<unsigned long long>();
     const uint32_t thr0 = std::min<uint32_t>(max_div, db->L);  // a distance never exceeds seq_len
     const uint32_t n_tiles = (uint32_t)((db->n + kWaveTile - 1) / kWaveTile);
@@ -819,6 +904,7 @@ int db_clear(smafa_db *db) {
     if (!db) return set_error(SMAFA_ERR_INVALID, "db_clear: NULL handle");
     db->n = 0;
     db->runs.clear();
+    db->rows_since_sort = 0;
     db->tile_bits.clear();
     for (uint64_t &h : db->zone_hist) h = 0;
     db->generation++;
@@ -958,6 +1044,7 @@ int db_load_packed(smafa_db **out, int device, const PackedStore &pk) {
     if (e != hipSuccess) return fail(set_error(SMAFA_ERR_DEVICE, "loading the packed store failed: %s", hipGetErrorString(e)));
     db->n = pk.h.n;
     for (uint64_t r = 0; r < pk.h.n_runs; r++) db->runs.push_back({pk.runs[2 * r], pk.runs[2 * r + 1] != 0});
+    db->rows_since_sort = pk.h.n_runs > 1 ? pk.h.n : 0;  // a file saved from a patchwork store: sorted at the first scan
     note_zone_words(db, 0, reinterpret_cast<const uint4 *>(pk.zone), pk.h.n_tiles);
     db->generation++;
     return SMAFA_OK;
@@ -1009,6 +1096,8 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     if (const char *wv = getenv("SMAFA_WIDE_FROM")) db->wide_from = (uint32_t)std::max(3, atoi(wv));
     if (const char *zv = getenv("SMAFA_ZONE")) db->zone = std::min(2, std::max(0, atoi(zv)));
     if (const char *sv = getenv("SMAFA_SORT")) db->sort_rows = atoi(sv) != 0;
+    if (const char *sv = getenv("SMAFA_RESORT")) db->resort = atoi(sv) != 0;
+    if (const char *sv = getenv("SMAFA_RESORT_MIN")) db->resort_min = std::max<uint64_t>(2, strtoull(sv, nullptr, 10));
     if (const char *zl = getenv("SMAFA_ZONE_LOOSE")) db->zone_loose = atof(zl);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) db->n_cu = prop.multiProcessorCount;
@@ -1044,6 +1133,7 @@ int smafa_db_append(smafa_db *db, const uint8_t *codes, uint64_t n) {
     rc = pack_rows(db, codes, db->n, n, db->d_planes, 0);
     if (rc) return rc;
     db->n += n;
+    db->rows_since_sort += n;
     db->generation++;
     if (n > (1u << 20)) {  // a bulk load's staging and sort buffers are not worth keeping
         for (DevBuf *b : {&db->upload, &db->keys_a, &db->keys_b, &db->idx_a, &db->idx_b, &db->sort_tmp}) b->release();
@@ -1059,6 +1149,8 @@ int smafa_db_save(smafa_db *db, const char *path) {
         rc = choose_layout(db, nullptr, 0);
         if (rc) return rc;
     }
+    rc = maybe_resort(db);  // a patchwork of appends is saved as one sorted run
+    if (rc) return rc;
     PackedHeader h{};
     h.alphabet = (uint32_t)db->alphabet;
     h.seq_len = db->L;

@@ -178,9 +178,12 @@ int pack_store_on_host(int alphabet, uint32_t L, const uint8_t *codes, uint64_t 
                 }
             }
             uint32_t *z = &zone[(size_t)tile * 4];  // zone_kernel
-            z[1] = ~(land[0] ^ lor[0]);
+            // (bits past the last column are zero in every subject and every query: not shared information)
+            const uint32_t cols0 = L >= 32 ? 0xffffffffu : (1u << L) - 1u;
+            const uint32_t cols1 = L >= 64 ? 0xffffffffu : L > 32 ? (1u << (L - 32)) - 1u : 0u;
+            z[1] = ~(land[0] ^ lor[0]) & cols0;
             z[0] = land[0] & z[1];
-            z[3] = W > 1 ? ~(land[1] ^ lor[1]) : 0u;
+            z[3] = W > 1 ? (~(land[1] ^ lor[1]) & cols1) : 0u;
             z[2] = W > 1 ? (land[1] & z[3]) : 0u;
         }
     });

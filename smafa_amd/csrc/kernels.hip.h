@@ -1749,10 +1749,34 @@ __global__ void row_keys_kernel(const uint8_t *__restrict__ codes, uint64_t n, u
     iota[i] = (uint32_t)i;
 }
 
+// Re-sorting a store in place (engine.hip resort_store): the key of the row at a position, read back from the filter
+// plane (the same key row_keys_kernel computes from the code bytes), and the move of every row to its new position.
+__global__ void position_keys_kernel(const uint32_t *__restrict__ planes, uint32_t PS, uint32_t W, uint64_t n,
+                                     unsigned long long *__restrict__ keys, uint32_t *__restrict__ iota) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *t = planes + (i >> 8) * ((size_t)PS * W * 256) + (i & 255u);  // plane 0 = the filter plane
+    const uint32_t w0 = t[0], w1 = W > 1 ? t[256] : 0u;
+    keys[i] = ((unsigned long long)gray_rank(w0) << 32) | gray_rank(w1);
+    iota[i] = (uint32_t)i;
+}
+
+__global__ void permute_rows_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                    const uint32_t *__restrict__ from, const uint32_t *__restrict__ order_in,
+                                    uint32_t *__restrict__ order_out, uint64_t n, uint32_t PW) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t old = from[p];
+    order_out[p] = order_in[old];
+    const uint32_t *s = in + (size_t)(old >> 8) * ((size_t)PW * 256) + (old & 255u);
+    uint32_t *d = out + (p >> 8) * ((size_t)PW * 256) + (p & 255u);
+    for (uint32_t j = 0; j < PW; j++) d[(size_t)j * 256] = s[(size_t)j * 256];
+}
+
 // zone[tile] = {c0, m0, c1, m1}: m_w = the bits of filter word w on which all subjects of the wave tile agree, c_w =
 // their common value there.  For a query word q, popcount((q ^ c_w) & m_w) mismatching columns are shared by every
 // subject of the tile.  One wave per tile; positions past n_subjects (the padding of the last tile) do not count.
-__global__ __launch_bounds__(256) void zone_kernel(const uint4 *__restrict__ planes, uint32_t PS, uint32_t W,
+__global__ __launch_bounds__(256) void zone_kernel(const uint4 *__restrict__ planes, uint32_t PS, uint32_t W, uint32_t L,
                                                    uint32_t tile_begin, uint32_t tile_end, uint32_t n_subjects,
                                                    uint4 *__restrict__ zone) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1781,9 +1805,13 @@ __global__ __launch_bounds__(256) void zone_kernel(const uint4 *__restrict__ pla
     }
     if (lane == 0) {
         uint4 z;
-        z.y = ~(land[0] ^ lor[0]);
+        // bits past the last column are zero in every subject and every query: they never mismatch, and counting them as
+        // shared would make the store look better sorted than it is (use_zone works from these words)
+        const uint32_t cols0 = L >= 32u ? 0xffffffffu : (1u << L) - 1u;
+        const uint32_t cols1 = L >= 64u ? 0xffffffffu : L > 32u ? (1u << (L - 32u)) - 1u : 0u;
+        z.y = ~(land[0] ^ lor[0]) & cols0;
         z.x = land[0] & z.y;
-        z.w = W > 1 ? ~(land[1] ^ lor[1]) : 0u;
+        z.w = W > 1 ? (~(land[1] ^ lor[1]) & cols1) : 0u;
         z.z = W > 1 ? (land[1] & z.w) : 0u;
         if (lor[0] == 0u && land[0] == 0xffffffffu) z = make_uint4(0u, 0u, 0u, 0u);  // an empty tile shares nothing
         zone[tile] = z;

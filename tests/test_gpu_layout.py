@@ -148,6 +148,53 @@ def test_appends_in_pieces_sorted_and_unsorted(zone_env, alphabet, n_letters):
     pieces.close()
 
 
+@pytest.mark.parametrize("alphabet,n_letters,L,D", [(1, 20, 60, 3), (0, 4, 60, 2), (0, 5, 100, 3), (1, 24, 20, 2)])
+def test_store_grown_by_small_appends_is_sorted_again(zone_env, tmp_path, alphabet, n_letters, L, D):
+    """a patchwork of appends (cluster's centroid set, a DB loaded in pieces) is sorted again on the device before a scan
+    once it has grown by a quarter since its last full sort: the zone kernel then runs on it, rows unchanged; SMAFA_RESORT=0
+    keeps the patchwork (and the kernel for it)"""
+    zone_env.pop("SMAFA_ZONE", None)
+    rng = np.random.default_rng(1000 + L + alphabet)
+    sizes = [3000] * 20 + [1, 255, 4500, 700]  # small (unsorted) and big (sorted one by one) appends
+    parts = [rng.integers(0, n_letters, size=(m, L), dtype=np.uint8) for m in sizes]
+    if alphabet == 0 and n_letters == 5:
+        parts = [np.minimum(p, 3) for p in parts]  # N comes later
+    s = np.concatenate(parts)
+    q = queries_from(rng, s, 300, min(n_letters, 4) if alphabet == 0 else n_letters, 5)
+    want = oracle.scan_codes(s, q, D)
+    os.environ["SMAFA_RESORT"] = "0"
+    try:
+        plain = smafa_amd.SubjectStore(L, alphabet)
+    finally:
+        os.environ.pop("SMAFA_RESORT")
+    store = smafa_amd.SubjectStore(L, alphabet)
+    for p_ in parts:
+        plain.push(p_)
+        store.push(p_)
+    assert plain.scan(q, max_divergence=D).tobytes() == want.tobytes()
+    assert not plain.last_scan_kernel().startswith("smafa::scan_zone")
+    assert store.scan(q, max_divergence=D).tobytes() == want.tobytes()
+    assert store.last_scan_kernel().startswith("smafa::scan_zone_kernel"), store.last_scan_kernel()
+    assert store.scan(q[:5], max_divergence=D).tobytes() == oracle.scan_codes(s, q[:5], D).tobytes()
+    assert store.scan(q, max_num_hits=1).tobytes() == expected_with_k(oracle.scan_codes(s, q, L), 1).tobytes()
+    assert (store.get_distances(q[1]) == oracle.distances_codes(s, q[1])).all()
+    # grows by less than a quarter: the tail stays a patch; then by more: sorted again.  Rows right either way.
+    more = [rng.integers(0, n_letters, size=(m, L), dtype=np.uint8) for m in (2000, 9000, 9000, 5)]
+    for i, m_ in enumerate(more):
+        store.push(m_)
+        s = np.concatenate([s, m_])
+        assert store.scan(q, max_divergence=D).tobytes() == oracle.scan_codes(s, q, D).tobytes(), i
+    path = str(tmp_path / "grown.packed")
+    store.save(path)
+    store.close()
+    plain.close()
+    back = smafa_amd.SubjectStore.load(path)
+    assert back.scan(q, max_divergence=D).tobytes() == oracle.scan_codes(s, q, D).tobytes()
+    back.close()
+    alphabet_back, codes = smafa_amd.read_db(path)
+    assert alphabet_back == alphabet and codes.tobytes() == s.tobytes()
+
+
 def test_sorted_and_unsorted_layouts_agree(zone_env):
     rng = np.random.default_rng(17)
     s = skewed_store(rng, 30000, 60, 20, families=100)

@@ -25,7 +25,8 @@ t_end, rounds, scans = time.time() + budget, 0, 0
 SWITCHES = {"SMAFA_FILTER": ["1", "1", "1", "0"], "SMAFA_LAZY": ["1", "1", "0"], "SMAFA_TILES": ["", "1", "2", "4"],
             "SMAFA_NT_PLANES": ["", "", "3"], "SMAFA_WIDE_FROM": ["5", "5", "3"], "SMAFA_WIDE_ONE": ["1", "1", "0"],
             "SMAFA_TWO_PHASE": ["1", "1", "0"], "SMAFA_COUNT_FIRST_K": ["3", "3", "2", "1000000"],
-            "SMAFA_ZONE": ["1", "1", "2", "2", "0"], "SMAFA_SORT": ["1", "1", "0"], "SMAFA_LAYOUT": ["1", "1", "0"]}
+            "SMAFA_ZONE": ["1", "1", "2", "2", "0"], "SMAFA_SORT": ["1", "1", "0"], "SMAFA_LAYOUT": ["1", "1", "0"],
+            "SMAFA_RESORT": ["1", "1", "1", "0"], "SMAFA_RESORT_MIN": ["", "2", "300", "5000"]}
 print("soak seed", seed0, flush=True)
 while time.time() < t_end:
     rng = np.random.default_rng(seed0 + rounds)
@@ -57,12 +58,18 @@ while time.time() < t_end:
     if nq > 3:
         q[0] = rng.integers(0, n_letters, size=L, dtype=np.uint8)
     store = smafa_amd.SubjectStore(L, alphabet)
-    for lo in range(0, n, max(1, n // int(rng.integers(1, 4)))):  # appended in 1-3 pieces
-        pass
     cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=int(rng.integers(0, 3)))]))
     for a, b in zip(cuts[:-1], cuts[1:]):
         store.push(s[a:b])
-    for _ in range(3):
+    for scan_no in range(4):
+        if scan_no == 3:  # the store grows between scans (a re-sort of the whole store may follow)
+            if rng.random() < 0.4:
+                break
+            extra = s[rng.integers(0, n, size=int(rng.choice([1, 300, max(1, n // 2), n])))].copy()
+            flip = rng.random(size=extra.shape) < 0.05
+            extra[flip] = rng.integers(0, n_letters, size=int(flip.sum()), dtype=np.uint8)
+            store.push(extra)
+            s = np.concatenate([s, extra])
         D = None if rng.random() < 0.25 else int(rng.integers(0, L + 1)) if rng.random() < 0.3 else int(rng.integers(0, min(L, 9) + 1))
         k = None if rng.random() < 0.4 else int(rng.choice([1, 1, 2, 3, 10, 400]))
         if D is None and k is None:
