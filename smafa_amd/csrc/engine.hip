@@ -515,11 +515,13 @@ static double zone_pass_share(const smafa_db *db, uint32_t thr0) {
 // `prunes`: does level 1 (word 0 of the filter plane) prune at this bound (prefilter_prunes)?  Where it does not — short
 // sequences, loose bounds: every (query, tile) pair that passes the zone level goes on to the exact comparison — the
 // zone level has to exclude more on its own to beat the all-planes kernel: SMAFA_ZONE_LOOSE (default 0.3).
-static bool use_zone(const smafa_db *db, uint32_t thr0, bool prunes) {
-    if (!db->lazy || !db->use_filter || db->W > 4) return false;
+static bool zone_pays(const smafa_db *db, uint32_t thr0, bool prunes) {
+    if (!db->lazy || !db->use_filter) return false;
     if (db->zone != 1) return db->zone == 2;
     return zone_pass_share(db, thr0) < (prunes ? 0.6 : db->zone_loose);
 }
+// up to 128 columns: scan_zone_kernel; longer: the zone level inside scan_wide_kernel (ScanArgs::zone_on)
+static bool use_zone(const smafa_db *db, uint32_t thr0, bool prunes) { return db->W <= 4 && zone_pays(db, thr0, prunes); }
 
 static uint32_t tiles_per_wave(const smafa_db *db, bool lazy) {
     if (lazy) return db->W >= 3 ? 2u : 4u;  // every filter word resident: 8 subjects per lane from 3 words on
@@ -539,7 +541,8 @@ static void launch_wide_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
     const uint32_t wc = (db->W == 3 || db->W == 4) ? db->W : 0u;  // compile-time word count: register-resident dense walk
 #define SMAFA_WIDE(FW_, WC_)                                                                                     \
     if (fw == FW_ && wc == WC_) {                                                                               \
-        note_kernel(db, "smafa::scan_wide_kernel<%d, %d, %s, %d, %d>", PS, PQ, seed ? "true" : "false", FW_, WC_); \
+        note_kernel(db, "smafa::scan_wide_kernel<%d, %d, %s, %d, %d>%s", PS, PQ, seed ? "true" : "false", FW_, WC_, \
+                    a.zone_on ? " (zone level on)" : "");                                                       \
         if (seed)                                                                                               \
             hipLaunchKernelGGL((scan_wide_kernel<PS, PQ, true, FW_, WC_>), dim3(grid), dim3(256), 0, db->stream, \
                                planes, d_qrec, a, db->W);                                                       \
@@ -649,6 +652,7 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     a.publish = publish;
     a.order = db->d_order;
     a.zone = db->d_zone;
+    a.zone_on = (wide && !zone && !seed && db->W > 4 && zone_pays(db, thr0, true)) ? 1u : 0u;
     const uint64_t n_qblocks = (q_end - q_begin + a.qb_size - 1) / a.qb_size;
     const uint64_t grid = n_qblocks * a.n_wg_tiles;
     if (grid > 0x7fffffffull)

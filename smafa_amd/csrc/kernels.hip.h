@@ -103,6 +103,7 @@ struct ScanArgs {
     const uint32_t *order;      // position in the packed store -> subject index (the order subjects were appended in)
     const uint4 *zone;          // per wave tile: {bits all its subjects share in filter word 0, which bits those are,
                                 //                 the same for word 1} — see zone_kernel
+    uint32_t zone_on;           // scan_wide_kernel: apply the zone level (the store is sorted well enough for it to pay)
 };
 
 // Where a workgroup parks qualifying rows between two flushes: one buffer per chunk parity, so that the rows of
@@ -1239,6 +1240,10 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
         }
     };
     load_filter();
+    // zone words of this wave's tiles (a.zone_on: a sorted store — see scan_zone_kernel): lane t holds tile slot t's
+    uint4 vz = make_uint4(0u, 0u, 0u, 0u);
+    const bool zone_on = !SEED && a.zone_on != 0;
+    if (zone_on && lane < (uint32_t)T && tile0 + lane < a.tile_end) vz = a.zone[tile0 + lane];
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
     const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
 
@@ -1433,14 +1438,44 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
             // pinned to scalars: hipcc cannot see through __ballot that these flags are wave-uniform
             const bool probe =
                 __builtin_amdgcn_readfirstlane((int)(a.use_filter && (filter_on || (chunk_no & 15u) == 0))) != 0;
-            const uint32_t *rec = reinterpret_cast<const uint32_t *>(&stage[buf][0]);
+            const uint32_t *rec0 = reinterpret_cast<const uint32_t *>(&stage[buf][0]);
             uint32_t passes = 0, level1_passes = 0;
             const bool l1 = __builtin_amdgcn_readfirstlane((int)level1_on) != 0;
             if (!probe) {
-                dense_walk(rec, nqc, qc);
+                dense_walk(rec0, nqc, qc);
                 load_filter();  // not kept across the walk: its registers hold the group's distances meanwhile
             }
-            for (uint32_t i = 0; probe && i < nqc; i++, rec += RS) {
+            // ---- zone level (sorted stores): lane i takes query i of the chunk; zq[t] = the queries tile slot t cannot
+            // exclude.  Off: every query, every tile.
+            unsigned long long zq[T], todo = nqc >= 64u ? ~0ull : (1ull << nqc) - 1ull;
+#pragma unroll
+            for (int t = 0; t < T; t++) zq[t] = todo;
+            if (probe && zone_on) {
+                uint4 head = make_uint4(0u, 0u, 0u, 0u);  // lanes past the chunk: ~bound = 0 never passes
+                if (lane < nqc) head = heads[buf][lane][0];
+                const uint32_t hnu = ONE ? head.y : head.z;
+                todo = 0ull;
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    const uint32_t zc0 = (uint32_t)__builtin_amdgcn_readlane((int)vz.x, t);
+                    const uint32_t zm0 = (uint32_t)__builtin_amdgcn_readlane((int)vz.y, t);
+                    uint32_t u = __builtin_popcount((head.x ^ zc0) & zm0) + hnu;
+                    if (!ONE) {
+                        const uint32_t zc1 = (uint32_t)__builtin_amdgcn_readlane((int)vz.z, t);
+                        const uint32_t zm1 = (uint32_t)__builtin_amdgcn_readlane((int)vz.w, t);
+                        u += __builtin_popcount((head.y ^ zc1) & zm1);
+                    }
+                    zq[t] = __ballot((int32_t)u < 0);
+                    todo |= zq[t];
+                }
+            }
+            while (probe && todo != 0ull) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const uint32_t *rec = rec0 + i * RS;
+                uint32_t tiles = 0;  // the tile slots this query still has to look at
+#pragma unroll
+                for (int t = 0; t < T; t++) tiles |= (uint32_t)((zq[t] >> i) & 1ull) << t;
                 uint32_t live = 0;
                 {
                     const uint4 head = heads[buf][i][0];  // one LDS read at a constant stride
@@ -1450,11 +1485,12 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
                         uint32_t any1 = 0;
 #pragma unroll
                         for (int t = 0; t < T; t++) {
+                            if (!((tiles >> t) & 1u)) continue;
                             const uint32_t u0 = __builtin_popcount(f[t][0].x ^ qw0) + nu;
                             const uint32_t u1 = __builtin_popcount(f[t][0].y ^ qw0) + nu;
                             const uint32_t u2 = __builtin_popcount(f[t][0].z ^ qw0) + nu;
                             const uint32_t u3 = __builtin_popcount(f[t][0].w ^ qw0) + nu;
-                            any1 = t ? or3(or3(u0, u1, u2), u3, any1) : (or3(u0, u1, u2) | u3);
+                            any1 = or3(or3(u0, u1, u2), u3, any1);
                         }
                         const bool go = __ballot((int32_t)any1 < 0) != 0ull;
                         level1_passes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(level1_passes + (go ? 1u : 0u)));
@@ -1468,6 +1504,7 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
                     if (NF >= 4) qf[3] = heads[buf][i][HV - 1].x;
 #pragma unroll
                     for (int t = 0; t < T; t++) {
+                        if (!((tiles >> t) & 1u)) continue;
                         uint32_t m0 = f[t][0].x ^ qf[0], m1 = f[t][0].y ^ qf[0];
                         uint32_t m2 = f[t][0].z ^ qf[0], m3 = f[t][0].w ^ qf[0];
 #pragma unroll

@@ -195,6 +195,34 @@ def test_store_grown_by_small_appends_is_sorted_again(zone_env, tmp_path, alphab
     assert alphabet_back == alphabet and codes.tobytes() == s.tobytes()
 
 
+@pytest.mark.parametrize("alphabet,n_letters,L", [(1, 20, 200), (0, 4, 150), (0, 5, 300), (1, 28, 129)])
+def test_zone_level_of_the_wide_kernel(zone_env, alphabet, n_letters, L):
+    """more than 128 columns: scan_wide_kernel applies the zone level itself when the store is sorted well enough"""
+    rng = np.random.default_rng(7 * L + alphabet)
+    s = rng.integers(0, n_letters, size=(40000, L), dtype=np.uint8)
+    s[100:200] = s[0:100]
+    q = queries_from(rng, s, 333, n_letters, 6)
+    rows = {}
+    for zone in ("1", "0", "2"):
+        zone_env["SMAFA_ZONE"] = zone
+        store = smafa_amd.SubjectStore(L, alphabet)
+        store.push(s[:30000])
+        store.push(s[30000:])
+        for D in (0, 3, 5):
+            got = store.scan(q, max_divergence=D)
+            assert got.tobytes() == oracle.scan_codes(s, q, D).tobytes(), (zone, D)
+            name = store.last_scan_kernel()
+            assert name.startswith("smafa::scan_wide_kernel"), name
+            if zone != "1" or D == 0:  # automatic: on where the tiles' shared bits exclude most queries (here: D = 0)
+                assert name.endswith("(zone level on)") == (zone != "0"), (zone, D, name)
+        rows[zone] = store.scan(q, max_num_hits=2, max_divergence=4).tobytes()
+        one = store.scan(q[:1], max_divergence=3)
+        assert one.tobytes() == oracle.scan_codes(s, q[:1], 3).tobytes()
+        store.close()
+    assert len(set(rows.values())) == 1
+    assert rows["1"] == expected_with_k(oracle.scan_codes(s, q, 4), 2).tobytes()
+
+
 def test_sorted_and_unsorted_layouts_agree(zone_env):
     rng = np.random.default_rng(17)
     s = skewed_store(rng, 30000, 60, 20, families=100)

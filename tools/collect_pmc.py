@@ -107,7 +107,7 @@ def main():
         if not line:
             print("no bench line in", name, "— see", os.path.join(out, name + ".log"))
             continue
-        kernel = line["roofline"]["kernel"]
+        kernel = line["roofline"]["kernel"].split(" (")[0]  # (a note like " (zone level on)" is not part of the symbol)
         cfg = line["config"]
         record["build_id"] = line.get("build_id")
         avg, nd, ms = per_launch(counter_rows(d), kernel.replace("smafa::", ""))
