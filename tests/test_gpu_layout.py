@@ -430,6 +430,19 @@ def test_packed_store_rejects_damaged_files(tmp_path):
         with pytest.raises(smafa_amd.SmafaError):
             smafa_amd.read_db(damaged(edit, name))
     smafa_amd.SubjectStore.load(damaged(lambda b: None, "same")).close()
+    # zone words are pruning metadata: a loader that believed a damaged copy would lose rows silently.  They are
+    # recomputed from the planes at load time, so garbage there changes nothing.
+    off_zone = struct.unpack_from("<Q", good, 8 + 40 + 40)[0]
+    n_tiles = struct.unpack_from("<Q", good, 8 + 24)[0]
+    q = queries_from(rng, s, 100, 4, 4)
+    os.environ["SMAFA_ZONE"] = "2"
+    try:
+        back = smafa_amd.SubjectStore.load(damaged(lambda b: b.__setitem__(slice(off_zone, off_zone + 16 * n_tiles), b"\xff" * (16 * n_tiles)), "zone"))
+    finally:
+        os.environ.pop("SMAFA_ZONE")
+    assert back.scan(q, max_divergence=3).tobytes() == oracle.scan_codes(s, q, 3).tobytes()
+    assert back.last_scan_kernel().startswith("smafa::scan_zone_kernel")
+    back.close()
 
 
 @pytest.mark.parametrize("alphabet,n_letters,n", [(0, 4, 3000), (0, 4, 30000), (0, 5, 12000), (1, 20, 30000), (1, 28, 5000)])
