@@ -445,15 +445,16 @@ def test_packed_store_rejects_damaged_files(tmp_path):
     back.close()
 
 
-@pytest.mark.parametrize("alphabet,n_letters,n", [(0, 4, 3000), (0, 4, 30000), (0, 5, 12000), (1, 20, 30000), (1, 28, 5000)])
-def test_host_packed_file_equals_device_saved_file(tmp_path, alphabet, n_letters, n):
+@pytest.mark.parametrize("alphabet,n_letters,n,L", [(0, 4, 3000, 60), (0, 4, 30000, 60), (0, 5, 12000, 60), (1, 20, 30000, 60),
+                                                    (1, 28, 5000, 60), (1, 20, 9000, 20), (0, 4, 9000, 40), (1, 24, 6000, 150)])
+def test_host_packed_file_equals_device_saved_file(tmp_path, alphabet, n_letters, n, L):
     """the host restatement of the device's packing (layout, stable sort by filter words, ballot bit-planes, order, zone
     words) must produce the SAME BYTES as smafa_db_save of a store packed by the kernels — an independent check of
     pack_rows_kernel, row_keys_kernel, the radix sort's stability and zone_kernel"""
     from smafa_amd import synth
 
     rng = np.random.default_rng(n + n_letters)
-    s = skewed_store(rng, n, 60, n_letters, families=30)
+    s = skewed_store(rng, n, L, n_letters, families=30)
     fa = str(tmp_path / "s.fa")
     synth.write_fasta(fa, s, alphabet)
     host, dev = str(tmp_path / "host.packed"), str(tmp_path / "dev.packed")
