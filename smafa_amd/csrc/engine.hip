@@ -425,9 +425,9 @@ static void launch_zone_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
     const bool fixed = a.thr == nullptr;  // one bound for every query: LDS-DMA staging, scalar bound
     note_kernel(db, "smafa::scan_zone_kernel<%d, %d, %d, %s>", PS, PQ, W, fixed ? "true" : "false");
     if (fixed)
-        hipLaunchKernelGGL((scan_zone_kernel<PS, PQ, W, true>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
+        hipLaunchKernelGGL((scan_zone_kernel<PS, PQ, W, true>), dim3(grid), dim3(kZoneWgWaves * 64), 0, db->stream, planes, d_qrec, a);
     else
-        hipLaunchKernelGGL((scan_zone_kernel<PS, PQ, W, false>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
+        hipLaunchKernelGGL((scan_zone_kernel<PS, PQ, W, false>), dim3(grid), dim3(kZoneWgWaves * 64), 0, db->stream, planes, d_qrec, a);
 }
 
 template <int PS, int PQ, int W, int T>
@@ -633,11 +633,14 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
                      : wide ? (uint32_t)kWideTiles : specialised ? tiles_per_wave(db, lazy) : (uint32_t)kGenericTiles;
     a.tile_begin = tile_begin;
     a.tile_end = tile_end;
-    a.n_wg_tiles = (tile_end - tile_begin + kWgWaves * T - 1) / (kWgWaves * T);
+    const uint32_t wg_waves = (zone && q_end - q_begin > 64u) ? (uint32_t)kZoneWgWaves : (uint32_t)kWgWaves;
+    a.n_wg_tiles = (tile_end - tile_begin + wg_waves * T - 1) / (wg_waves * T);
     a.n_subjects = (uint32_t)db->n;
     a.q_begin = q_begin;
     a.q_end = q_end;
-    a.qb_size = choose_query_block(db, a.n_wg_tiles, q_end - q_begin);
+    // (the block size is chosen per 4-wave share of the store whatever the workgroup size, so that it does not change
+    // with kZoneWgWaves: profiles/r02_zone_variants.txt)
+    a.qb_size = choose_query_block(db, (tile_end - tile_begin + kWgWaves * T - 1) / (kWgWaves * T), q_end - q_begin);
     // fixed common bound: no per-query array, no fill launch; per_query_bounds: fixed bounds read from thr
     a.thr = (k_tight || per_query_bounds) ? qs->thr.as<uint32_t>() : nullptr;
     a.thr0 = thr0;

@@ -108,11 +108,14 @@ struct ScanArgs {
 
 // Where a workgroup parks qualifying rows between two flushes: one buffer per chunk parity, so that the rows of
 // chunk k are written out while chunk k+1 already appends to the other buffer (no extra barrier on the common path).
-struct RowStage {
-    smafa_hit rows[2][kStageRows];
-    uint32_t n[2];            // rows parked (may run past kStageRows: the excess went straight to the list)
+template <int ROWS>
+struct RowStageT {
+    static constexpr int kRows = ROWS;
+    smafa_hit rows[2][ROWS];
+    uint32_t n[2];            // rows parked (may run past ROWS: the excess went straight to the list)
     unsigned long long base;  // the flushing thread's reservation, read by the whole workgroup
 };
+using RowStage = RowStageT<kStageRows>;
 
 // acc | (s ^ q) in one VALU op.  Truth table over (a=0xF0, b=0xCC, c=0xAA): 0xF0 | (0xCC ^ 0xAA) = 0xF6.
 __device__ __forceinline__ uint32_t or_xor(uint32_t acc, uint32_t s, uint32_t q) {
@@ -144,7 +147,8 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int
 // Correctness of tightening: thr[q] is only lowered to a distance d once at least k subjects with
 // distance <= d have been counted, so thr[q] >= (k-th smallest distance of q) at all times and every
 // subject within the true bound passes `dist <= thr` whenever it is visited.
-__device__ __forceinline__ void emit(const ScanArgs &a, RowStage &rs, int parity, uint32_t q, uint32_t pos, uint32_t dist) {
+template <int ROWS>
+__device__ __forceinline__ void emit(const ScanArgs &a, RowStageT<ROWS> &rs, int parity, uint32_t q, uint32_t pos, uint32_t dist) {
     if (a.hits) {
         // The lanes that got here together (a wave works on one query at a time, so they all append for the same
         // query) take consecutive slots of the workgroup's LDS stage: one LDS atomic per wave (v_mbcnt ranks the lanes).
@@ -159,7 +163,7 @@ __device__ __forceinline__ void emit(const ScanArgs &a, RowStage &rs, int parity
         if ((int)lane == leader) base = atomicAdd(&rs.n[parity], (uint32_t)__builtin_popcountll(together));
         base = (uint32_t)__shfl((int)base, leader, 64);
         const uint32_t slot = base + lanes_below(together);
-        if (slot < (uint32_t)kStageRows) {
+        if (slot < (uint32_t)ROWS) {
             rs.rows[parity][slot] = h;
         } else {
             // the stage is full until the next flush (a dense neighbourhood): straight to the list, one atomic per wave
@@ -186,10 +190,11 @@ __device__ __forceinline__ void emit(const ScanArgs &a, RowStage &rs, int parity
 // Write the rows parked under `parity` out to the list.  Called by EVERY thread of the workgroup right after the
 // barrier that ends a chunk: nobody appends to this parity again before the next chunk's barrier, so n is stable and
 // the branch is uniform.
-__device__ __forceinline__ void flush_rows(const ScanArgs &a, RowStage &rs, int parity) {
+template <int ROWS>
+__device__ __forceinline__ void flush_rows(const ScanArgs &a, RowStageT<ROWS> &rs, int parity) {
     const uint32_t parked = rs.n[parity];
     if (parked == 0) return;
-    const uint32_t n = min(parked, (uint32_t)kStageRows);
+    const uint32_t n = min(parked, (uint32_t)ROWS);
     if (threadIdx.x == 0) rs.base = atomicAdd(a.count, (unsigned long long)n);
     __syncthreads();
     const unsigned long long base = rs.base;
@@ -756,6 +761,13 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
 #define SMAFA_ZONE_TILES 4
 #endif
 constexpr int kZoneTiles = SMAFA_ZONE_TILES;
+// Waves per workgroup of scan_zone_kernel.  The waves of a workgroup share the staged query chunk and meet at one barrier
+// per chunk; fewer waves per workgroup wait less for each other and stage more often.  Measured (profiles/
+// r02_zone_variants.txt): 4 / 2 / 1 waves: aa 1.988 / 1.958 / 1.998 ms, nt (bound 3) 4.079 / 3.953 / 4.044 ms.
+#ifndef SMAFA_ZONE_WG_WAVES
+#define SMAFA_ZONE_WG_WAVES 2
+#endif
+constexpr int kZoneWgWaves = SMAFA_ZONE_WG_WAVES;
 #ifndef SMAFA_FEW_TILES
 #define SMAFA_FEW_TILES 4
 #endif
@@ -772,18 +784,20 @@ __host__ __device__ constexpr int zone_min_waves(int ps, int w) { return ps * w 
 // across every chunk, 1.2 GB of scratch writes per launch), nothing has to be merged into the records, and ~bound is a
 // scalar.  !FIXED (per-query bounds that tighten while the scan runs): register prefetch, ~bound merged at fetch time.
 template <int PS, int PQ, int W, bool FIXED>
-__global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(const uint4 *__restrict__ planes,
+__global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan_zone_kernel(const uint4 *__restrict__ planes,
                                                            const uint32_t *__restrict__ qrec, ScanArgs a) {
     constexpr int T = kZoneTiles;
     constexpr int RS = qrec_stride(PQ, W);
     constexpr int RV = RS / 4;
-    constexpr int NV = (kChunk * RV + 255) / 256;
+    constexpr int WGW = kZoneWgWaves;  // waves per workgroup
+    constexpr int NT = WGW * 64;
+    constexpr int NV = (kChunk * RV + NT - 1) / NT;
     constexpr int FP = filter_plane(PQ);
     constexpr int BS = bound_slot(W);
     constexpr bool kPair = SMAFA_AND_PAIR && W > 1;
     __shared__ uint4 stage[2][kChunk * RV];
     __shared__ uint32_t nu_lds[2][kChunk];  // !FIXED: ~bound of the staged queries
-    __shared__ RowStage rs;
+    __shared__ RowStageT<(WGW == 1 ? 64 : kStageRows)> rs;
     int buf = 0;  // LDS buffer of the chunk being computed = parity of the row stage it appends to
 
     const uint32_t tid = threadIdx.x;
@@ -792,7 +806,7 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
     if (tid == 0) rs.n[0] = rs.n[1] = 0;  // published by the barrier in front of the chunk loop
     const uint32_t wg_tile = blockIdx.x % a.n_wg_tiles;
     const uint32_t qblock = blockIdx.x / a.n_wg_tiles;
-    const uint32_t tile0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.tile_begin + (wg_tile * kWgWaves + wave) * T));
+    const uint32_t tile0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.tile_begin + (wg_tile * WGW + wave) * T));
     const bool active = tile0 < a.tile_end;
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
     const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
@@ -830,10 +844,10 @@ __global__ __launch_bounds__(256, zone_min_waves(PS, W)) void scan_zone_kernel(c
         const uint4 *src = reinterpret_cast<const uint4 *>(qrec + (size_t)qc * RS);
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-            const uint32_t idx = tid + v * 256;
+            const uint32_t idx = tid + v * NT;
             if (idx < nqc * RV)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + idx),
-                                                 (__attribute__((address_space(3))) void *)(&stage[b][wave * 64 + v * 256]), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(&stage[b][wave * 64 + v * NT]), 16, 0, 0);
         }
     };
     const uint32_t nu0 = ~a.thr0;  // FIXED: every query's ~bound
