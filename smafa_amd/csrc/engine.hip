@@ -109,6 +109,7 @@ struct smafa_db {
     uint64_t rows_since_sort = 0;  // rows appended since the whole store was last in one sorted run
     uint32_t resorts = 0;          // full re-sorts so far (resort_store)
     bool resort = true;            // SMAFA_RESORT=0: never
+    double prune_p = 2e-3;         // prefilter_prunes: largest level-1 pass probability per subject (SMAFA_PRUNE_P)
     uint64_t resort_min = 32768;   // stores below this many rows are left alone (SMAFA_RESORT_MIN)
     double zone_loose = 0.3;      // pass share below which the zone kernel also takes bounds level 1 cannot prune at (SMAFA_ZONE_LOOSE)
     int zone = 1;                 // zone level of the filter-plane-resident kernel: 1 = where it prunes (use_zone), 0 = never
@@ -464,7 +465,7 @@ static bool prefilter_prunes(const smafa_db *db, uint32_t bound) {
         term = term * (double)(cols - k) / (double)(k + 1);
     }
     for (uint32_t i = 0; i < cols; i++) tail *= 0.5;
-    return tail <= 2e-3;
+    return tail <= db->prune_p;
 }
 
 static bool use_lazy(const smafa_db *db, uint32_t thr0) {
@@ -515,13 +516,24 @@ static double zone_pass_share(const smafa_db *db, uint32_t thr0) {
 // `prunes`: does level 1 (word 0 of the filter plane) prune at this bound (prefilter_prunes)?  Where it does not — short
 // sequences, loose bounds: every (query, tile) pair that passes the zone level goes on to the exact comparison — the
 // zone level has to exclude more on its own to beat the all-planes kernel: SMAFA_ZONE_LOOSE (default 0.3).
-static bool zone_pays(const smafa_db *db, uint32_t thr0, bool prunes) {
+// Bounds between the two regimes (level 1 no longer prunes, the tiles' shared bits exclude little): on a well sorted
+// two-word store scan_zone_kernel still beats the all-planes kernel up to a bound of 3/8 of the first 32 columns — its
+// level 2 (the filter plane over all columns) rejects what level 1 lets through, for a quarter of the all-planes
+// kernel's instructions.  tools/bound_probe.py, profiles/r02_bound_probe.txt, 10 000 queries, zone kernel vs all-planes:
+// aa 10M bound 10: 14.1 vs 28.7 ms, bound 12: 23.0 vs 30.2, bound 14: 41.5 vs 30.7; aa 1M bound 12: 2.5 vs 3.2;
+// nucleotides (2 planes: the all-planes kernel is cheap) only with per-query bounds that tighten: bound 12 13.8 vs 16.1.
+static bool zone_pays(const smafa_db *db, uint32_t thr0, bool prunes, bool tightening = false) {
     if (!db->lazy || !db->use_filter) return false;
     if (db->zone != 1) return db->zone == 2;
-    return zone_pass_share(db, thr0) < (prunes ? 0.6 : db->zone_loose);
+    if (zone_pass_share(db, thr0) < (prunes ? 0.6 : db->zone_loose)) return true;
+    const uint32_t cols = std::min<uint32_t>(32u, db->L);
+    return !prunes && db->W == 2 && thr0 <= 3u * cols / 8u && (db->P >= 5 || tightening) &&
+           zone_pass_share(db, (cols - 1u) / 6u) < 0.6;
 }
 // up to 128 columns: scan_zone_kernel; longer: the zone level inside scan_wide_kernel (ScanArgs::zone_on)
-static bool use_zone(const smafa_db *db, uint32_t thr0, bool prunes) { return db->W <= 4 && zone_pays(db, thr0, prunes); }
+static bool use_zone(const smafa_db *db, uint32_t thr0, bool prunes, bool tightening) {
+    return db->W <= 4 && zone_pays(db, thr0, prunes, tightening);
+}
 
 static uint32_t tiles_per_wave(const smafa_db *db, bool lazy) {
     if (lazy) return db->W >= 3 ? 2u : 4u;  // every filter word resident: 8 subjects per lane from 3 words on
@@ -627,7 +639,7 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     const bool seed = d_rows == nullptr && k_tight == 1;  // the seed pass covers a few tiles: no zone level
     // a sorted store whose tiles share enough bits takes the zone kernel at any length up to 128 columns — also where
     // scan_wide_kernel would otherwise run (one-word stores)
-    const bool zone = specialised && !seed && use_zone(db, thr0, prefilter_prunes(db, thr0));
+    const bool zone = specialised && !seed && use_zone(db, thr0, prefilter_prunes(db, thr0), k_tight != 0 || per_query_bounds);
     lazy = lazy || zone;  // (the plan reported by smafa_last_scan_plan: a filter-plane-resident kernel)
     const uint32_t T = zone ? (q_end - q_begin <= 64u ? (uint32_t)kFewTiles : (uint32_t)kZoneTiles)
                      : wide ? (uint32_t)kWideTiles : specialised ? tiles_per_wave(db, lazy) : (uint32_t)kGenericTiles;
@@ -932,71 +944,96 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
     if (rc) return rc;
     rc = qset_fill(&db->scratch_q, db, query_codes, n_queries);
     if (rc) return rc;
-    bool collected = false;
-    // k-th-distance modes whose bound is loose or absent (`smafa query` without --max-divergence): the scan would
-    // run the all-planes kernel until each query's running bound has tightened.  Most queries of real inputs have
-    // their k nearest subjects within a few mismatches, so first ask the cheap question — a scan whose bound starts
-    // at a value the prefilter prunes well at (d0).  A query with at least k rows within d0 is finished:
-    // its k-th smallest distance is <= d0, so every row it may print is among them.  Only the other queries take
-    // the tightening path, as a compacted batch.  Exact either way; when no query is finished the probe costs one
-    // fast launch (~10 % of the slow path), when d0 already overflows the buffer it is abandoned.
+    // k-th-distance modes whose bound is loose or absent (`smafa query` without --max-divergence — the reference's
+    // default): the scan would run the all-planes kernel until each query's running bound has tightened.  Most queries
+    // of real inputs have their k nearest subjects within a few mismatches, so first ask the cheap questions: a LADDER of
+    // scans whose bound starts at a value the filter kernels still handle well (5, then 10 of the first 32 columns —
+    // doubling, the distribution of the nearest distances being unknown), each over the queries the step before left
+    // open.  A query with at least k rows within a step's bound is
+    // finished: its k-th smallest distance is <= that bound, so every row it may print is among them.  Whoever is
+    // left takes the tightening path, as a compacted batch.  Exact at every step.  A step that finishes fewer than an
+    // eighth of its queries is the last one (data without near neighbours pays for one cheap step only).
+    // Measured, 10 000 queries x 10M aa subjects, best hit, per step (tools/bound_probe.py, profiles/
+    // r02_bound_probe.txt): bound 5 2.1 ms, 8 7.3 ms, 10 11.4 ms, 12 16.7 ms, no bound 28.6 ms; nucleotides 1.8, 6.3,
+    // 9.7, 13.8, 16.7.
     const uint32_t k_mode = max_num_hits == SMAFA_NONE ? 0u : max_num_hits;
-    // d0: the prefilter's first level looks at min(32, L) columns of one plane; at a bound of a sixth of them it
-    // still rejects all but a few percent of the (wave, query) steps (measured: the launch costs the same at
-    // bound 5 as at bound 3 for L = 60, 2-3x more at bound 7)
-    const uint32_t d0 = (std::min<uint32_t>(32u, db->L) - 1u) / 6u;
-    if (k_mode >= 1 && std::min<uint32_t>(max_div, db->L) > d0 && db->use_filter && db->lazy && db->two_phase &&
-        n_queries >= 16) {
-        const uint32_t nq = (uint32_t)n_queries;
+    const uint32_t cols = std::min<uint32_t>(32u, db->L);
+    // first step: level 1 looks at `cols` columns of one plane; at a bound of a sixth of them it still rejects all but
+    // a few percent of the (wave, query) steps
+    std::vector<uint32_t> ladder = {(cols - 1u) / 6u, 5u * cols / 16u};
+    const uint32_t limit = std::min<uint32_t>(max_div, db->L);
+    std::vector<smafa_hit> done;      // rows of the finished queries (the caller's query numbers), ordered
+    std::vector<uint32_t> ids;        // open queries: position in the current batch -> the caller's number (empty: same)
+    std::vector<uint8_t> open_codes;  // ... and their code rows
+    const uint8_t *cur = query_codes;
+    uint32_t cur_n = (uint32_t)n_queries;
+    smafa_qset *qs = &db->scratch_q;
+    auto merge_done = [&](std::vector<smafa_hit> &more) {  // both ordered, disjoint queries
+        if (done.empty()) {
+            done.swap(more);
+            return;
+        }
+        std::vector<smafa_hit> all(done.size() + more.size());
+        std::merge(done.begin(), done.end(), more.begin(), more.end(), all.begin(), hit_less);
+        done.swap(all);
+    };
+    const bool laddered = k_mode >= 1 && db->use_filter && db->lazy && db->two_phase && n_queries >= 16;
+    for (size_t step = 0; laddered && step < ladder.size() && cur_n >= 16; step++) {
+        const uint32_t bound = ladder[step];
+        if (limit <= bound || (step > 0 && bound <= ladder[step - 1])) break;
         unsigned long long count = 0;
-        // the probe itself runs in the tightening mode (bound d0, lowered to each query's k-th distance as the scan
-        // proceeds), so on dense stores only the rows within the final bound come back, not every pair within d0
-        rc = scan_range(db, &db->scratch_q, 0, nq, d0, k_mode, db->hits.as<smafa_hit>(), db->hits_cap(),
+        // the step itself runs in the tightening mode (bound lowered to each query's k-th distance as the scan
+        // proceeds), so on dense stores only the rows within the final bound come back, not every pair within it
+        rc = scan_range(db, qs, 0, cur_n, bound, k_mode, db->hits.as<smafa_hit>(), db->hits_cap(),
                         db->count.as<unsigned long long>());
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(&count, db->count.p, sizeof count, hipMemcpyDeviceToHost, db->stream));
         HIP_TRY(hipStreamSynchronize(db->stream));
-        if (count > 0 && count <= db->hits_cap()) {
-            std::vector<smafa_hit> near;
-            rc = fetch_rows(db, count, 0, nq, near);
-            if (rc) return rc;
-            std::vector<uint32_t> have(nq, 0);
-            for (const smafa_hit &h : near) have[h.query]++;
-            std::vector<uint32_t> rest;  // queries that still need the full answer, ascending
-            for (uint32_t q = 0; q < nq; q++)
-                if (have[q] < k_mode) rest.push_back(q);
-            if (rest.size() < nq) {
-                std::vector<smafa_hit> far;
-                if (!rest.empty()) {
-                    std::vector<uint8_t> rest_codes(rest.size() * (size_t)db->L);
-                    for (size_t i = 0; i < rest.size(); i++)
-                        memcpy(&rest_codes[i * db->L], query_codes + (size_t)rest[i] * db->L, db->L);
-                    rc = qset_fill(&db->scratch_q2, db, rest_codes.data(), rest.size());
-                    if (rc) return rc;
-                    rc = collect_range(db, &db->scratch_q2, 0, (uint32_t)rest.size(), max_div, max_num_hits, far);
-                    if (rc) return rc;
-                    for (smafa_hit &h : far) h.query = rest[h.query];  // ascending map: order is kept
-                }
-                // both lists are ordered and cover disjoint queries
-                out.reserve(near.size() + far.size());
-                size_t a = 0, b = 0;
-                while (a < near.size() || b < far.size()) {
-                    if (a < near.size() && have[near[a].query] < k_mode) {  // superseded by the full answer
-                        a++;
-                        continue;
-                    }
-                    if (b == far.size() || (a < near.size() && near[a].query < far[b].query)) out.push_back(near[a++]);
-                    else out.push_back(far[b++]);
-                }
-                collected = true;
-                log_line(2, "near-hit probe at bound %u finished %u of %u queries", d0, nq - (uint32_t)rest.size(), nq);
-            }
-        }
-    }
-    if (!collected) {
-        rc = collect_range(db, &db->scratch_q, 0, (uint32_t)n_queries, max_div, max_num_hits, out);
+        if (count == 0 || count > db->hits_cap()) break;  // nobody near / too dense to look at: the full path decides
+        std::vector<smafa_hit> near;
+        rc = fetch_rows(db, count, 0, cur_n, near);
         if (rc) return rc;
+        std::vector<uint32_t> have(cur_n, 0);
+        for (const smafa_hit &h : near) have[h.query]++;
+        std::vector<uint32_t> open;  // positions in the current batch that still need an answer, ascending
+        for (uint32_t q = 0; q < cur_n; q++)
+            if (have[q] < k_mode) open.push_back(q);
+        if (open.size() == cur_n) break;
+        std::vector<smafa_hit> fin;
+        fin.reserve(near.size());
+        for (smafa_hit h : near)
+            if (have[h.query] >= k_mode) {
+                if (!ids.empty()) h.query = ids[h.query];  // ascending map: the order is kept
+                fin.push_back(h);
+            }
+        merge_done(fin);
+        log_line(2, "near-hit step at bound %u finished %u of %u queries", bound, cur_n - (uint32_t)open.size(), cur_n);
+        const bool paid = (uint64_t)(cur_n - open.size()) * 8u >= cur_n;
+        std::vector<uint32_t> next_ids(open.size());
+        std::vector<uint8_t> next_codes(open.size() * (size_t)db->L);
+        for (size_t i = 0; i < open.size(); i++) {
+            next_ids[i] = ids.empty() ? open[i] : ids[open[i]];
+            memcpy(&next_codes[i * db->L], cur + (size_t)open[i] * db->L, db->L);
+        }
+        ids.swap(next_ids);
+        open_codes.swap(next_codes);
+        cur = open_codes.data();
+        cur_n = (uint32_t)open.size();
+        if (cur_n == 0) break;
+        rc = qset_fill(&db->scratch_q2, db, cur, cur_n);
+        if (rc) return rc;
+        qs = &db->scratch_q2;
+        if (!paid) break;
     }
+    if (cur_n > 0) {
+        std::vector<smafa_hit> far;
+        rc = collect_range(db, qs, 0, cur_n, max_div, max_num_hits, far);
+        if (rc) return rc;
+        if (!ids.empty())
+            for (smafa_hit &h : far) h.query = ids[h.query];
+        merge_done(far);
+    }
+    out.swap(done);
     if (max_num_hits != SMAFA_NONE && max_num_hits >= 1) {
         // drop rows above the k-th smallest distance of their query (the device bound only tightens)
         size_t w = 0, i = 0;
@@ -1115,6 +1152,7 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     if (const char *zv = getenv("SMAFA_ZONE")) db->zone = std::min(2, std::max(0, atoi(zv)));
     if (const char *sv = getenv("SMAFA_SORT")) db->sort_rows = atoi(sv) != 0;
     if (const char *sv = getenv("SMAFA_RESORT")) db->resort = atoi(sv) != 0;
+    if (const char *sv = getenv("SMAFA_PRUNE_P")) db->prune_p = atof(sv);
     if (const char *sv = getenv("SMAFA_RESORT_MIN")) db->resort_min = std::max<uint64_t>(2, strtoull(sv, nullptr, 10));
     if (const char *zl = getenv("SMAFA_ZONE_LOOSE")) db->zone_loose = atof(zl);
     hipDeviceProp_t prop;

@@ -192,15 +192,15 @@ def test_kth_bound_modes(k, max_div):
 
 @pytest.mark.parametrize("alphabet,n_letters", [(0, 4), (1, 20)])
 def test_near_hit_probe_boundaries(alphabet, n_letters):
-    """k-th-distance modes with a loose or absent bound: a fixed-bound probe (bound 5 at L = 60) finishes the queries
-    with at least k rows within it, the rest take the tightening path as a compacted batch; queries sit exactly on
-    both sides of that boundary, with ties"""
+    """k-th-distance modes with a loose or absent bound: a ladder of bounded scans (bounds 5, then 10 at L = 60) finishes
+    the queries with at least k rows within a step's bound, the rest take the tightening path as a compacted batch;
+    queries sit exactly on both sides of both boundaries, with ties"""
     rng = np.random.default_rng(31 + alphabet)
     L, n = 60, 20000
     s = rng.integers(0, n_letters, size=(n, L), dtype=np.uint8)
     s[5000:5003] = s[17]              # 4 copies of row 17 in all: ties at distance 0 ...
     qs = []
-    for subs in (0, 1, 4, 5, 5, 6, 6, 7, 12, 30):     # ... and queries at 0..30 substitutions from their subject
+    for subs in (0, 1, 4, 5, 5, 6, 6, 7, 9, 10, 10, 11, 11, 12, 30):  # ... and queries at 0..30 substitutions from their subject
         for base in (17, 400, 4242, 19999):
             r = s[base].copy()
             cols = rng.choice(L, size=subs, replace=False)
@@ -210,7 +210,7 @@ def test_near_hit_probe_boundaries(alphabet, n_letters):
     q = np.array(qs, dtype=np.uint8)
     store = smafa_amd.SubjectStore(L, alphabet)
     store.push(s)
-    for D in (None, 6, 20):
+    for D in (None, 6, 10, 11, 20):
         full = oracle.scan_codes(s, q, L if D is None else D)
         for k in (1, 2, 4, 5, 60):
             got = store.scan(q, max_divergence=D, max_num_hits=k)
