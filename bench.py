@@ -400,6 +400,9 @@ def main() -> int:
         streamed = info.hbm_bytes * sb / info.bytes_per_subject
         alg = N * L * (8 if args.alphabet == "aa" else int(info.planes)) / 8
         ceiling = smafa_amd.hbm_read_probe(local_rank, 8 << 30)
+        # the same trivial sum over as many bytes as one pass streams (a launch this short is mostly ramp and tail; a
+        # buffer below 256 MB is also served by the Infinity Cache on repeats — as the store's plane is here)
+        ceiling_same = smafa_amd.hbm_read_probe(local_rank, int(streamed))
         stream_info = {
             "shipped": {"kernel": kern_z, "ms_per_query_wall": wall_z, "kernel_ms_median": k_z, "launches_per_query": launches_z,
                         "algorithmic_x_of_peak": alg / k_z / 1e6 / HBM_PEAK_GBS, "rows": rows_z},
@@ -412,13 +415,16 @@ def main() -> int:
             "rows_identical": rows_z == rows_s,
             "empirical_read_ceiling_GBs": ceiling,
             "empirical_read_ceiling_frac_of_peak": ceiling / HBM_PEAK_GBS,
+            "trivial_read_of_the_streamed_bytes_GBs": ceiling_same,
+            "streaming_kernel_vs_trivial_read_of_the_same_bytes": (streamed / k_s1 / 1e6) / ceiling_same if ceiling_same else None,
             "note": "one query per store pass. `shipped`: the default path (zone level: only the tiles the query survives "
                     "are fetched, so the pass is not a stream of the store and no streamed fraction is claimed for it). "
                     "`streaming`: the same pass with the zone level off (smafa_set_zone_level 0) — the kernel streams the "
                     "prefilter's bit-plane of every subject: frac_kernel_streamed / frac_wall_streamed = those bytes over "
                     "kernel time / wall time per query as a fraction of 8 TB/s; algorithmic_x_of_peak = %g B/subject over "
                     "kernel time (a reuse figure, not an efficiency); empirical ceiling = smafa_hbm_read_probe, a trivial "
-                    "sum over 8 GiB on this box" % (alg / N),
+                    "sum over 8 GiB on this box; trivial_read_of_the_streamed_bytes = the same sum over as many bytes as "
+                    "one pass streams (what a launch of that size can reach at all)" % (alg / N),
         }
         one.close()
 
