@@ -516,24 +516,13 @@ static double zone_pass_share(const smafa_db *db, uint32_t thr0) {
 // `prunes`: does level 1 (word 0 of the filter plane) prune at this bound (prefilter_prunes)?  Where it does not — short
 // sequences, loose bounds: every (query, tile) pair that passes the zone level goes on to the exact comparison — the
 // zone level has to exclude more on its own to beat the all-planes kernel: SMAFA_ZONE_LOOSE (default 0.3).
-// Bounds between the two regimes (level 1 no longer prunes, the tiles' shared bits exclude little): on a well sorted
-// two-word store scan_zone_kernel still beats the all-planes kernel up to a bound of 3/8 of the first 32 columns — its
-// level 2 (the filter plane over all columns) rejects what level 1 lets through, for a quarter of the all-planes
-// kernel's instructions.  tools/bound_probe.py, profiles/r02_bound_probe.txt, 10 000 queries, zone kernel vs all-planes:
-// aa 10M bound 10: 14.1 vs 28.7 ms, bound 12: 23.0 vs 30.2, bound 14: 41.5 vs 30.7; aa 1M bound 12: 2.5 vs 3.2;
-// nucleotides (2 planes: the all-planes kernel is cheap) only with per-query bounds that tighten: bound 12 13.8 vs 16.1.
-static bool zone_pays(const smafa_db *db, uint32_t thr0, bool prunes, bool tightening = false) {
+static bool zone_pays(const smafa_db *db, uint32_t thr0, bool prunes) {
     if (!db->lazy || !db->use_filter) return false;
     if (db->zone != 1) return db->zone == 2;
-    if (zone_pass_share(db, thr0) < (prunes ? 0.6 : db->zone_loose)) return true;
-    const uint32_t cols = std::min<uint32_t>(32u, db->L);
-    return !prunes && db->W == 2 && thr0 <= 3u * cols / 8u && (db->P >= 5 || tightening) &&
-           zone_pass_share(db, (cols - 1u) / 6u) < 0.6;
+    return zone_pass_share(db, thr0) < (prunes ? 0.6 : db->zone_loose);
 }
 // up to 128 columns: scan_zone_kernel; longer: the zone level inside scan_wide_kernel (ScanArgs::zone_on)
-static bool use_zone(const smafa_db *db, uint32_t thr0, bool prunes, bool tightening) {
-    return db->W <= 4 && zone_pays(db, thr0, prunes, tightening);
-}
+static bool use_zone(const smafa_db *db, uint32_t thr0, bool prunes) { return db->W <= 4 && zone_pays(db, thr0, prunes); }
 
 static uint32_t tiles_per_wave(const smafa_db *db, bool lazy) {
     if (lazy) return db->W >= 3 ? 2u : 4u;  // every filter word resident: 8 subjects per lane from 3 words on
@@ -639,7 +628,7 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     const bool seed = d_rows == nullptr && k_tight == 1;  // the seed pass covers a few tiles: no zone level
     // a sorted store whose tiles share enough bits takes the zone kernel at any length up to 128 columns — also where
     // scan_wide_kernel would otherwise run (one-word stores)
-    const bool zone = specialised && !seed && use_zone(db, thr0, prefilter_prunes(db, thr0), k_tight != 0 || per_query_bounds);
+    const bool zone = specialised && !seed && use_zone(db, thr0, prefilter_prunes(db, thr0));
     lazy = lazy || zone;  // (the plan reported by smafa_last_scan_plan: a filter-plane-resident kernel)
     const uint32_t T = zone ? (q_end - q_begin <= 64u ? (uint32_t)kFewTiles : (uint32_t)kZoneTiles)
                      : wide ? (uint32_t)kWideTiles : specialised ? tiles_per_wave(db, lazy) : (uint32_t)kGenericTiles;
@@ -947,20 +936,20 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
     // k-th-distance modes whose bound is loose or absent (`smafa query` without --max-divergence — the reference's
     // default): the scan would run the all-planes kernel until each query's running bound has tightened.  Most queries
     // of real inputs have their k nearest subjects within a few mismatches, so first ask the cheap questions: a LADDER of
-    // scans whose bound starts at a value the filter kernels still handle well (5, then 10 of the first 32 columns —
-    // doubling, the distribution of the nearest distances being unknown), each over the queries the step before left
-    // open.  A query with at least k rows within a step's bound is
+    // scans whose bound starts at a value the prefilters still handle well (5 of the first 32 columns: level 1 prunes,
+    // zone kernel; then 12: the per-subject folded bound of the all-planes kernel still rejects nearly every pair), each
+    // over the queries the step before left open.  A query with at least k rows within a step's bound is
     // finished: its k-th smallest distance is <= that bound, so every row it may print is among them.  Whoever is
     // left takes the tightening path, as a compacted batch.  Exact at every step.  A step that finishes fewer than an
     // eighth of its queries is the last one (data without near neighbours pays for one cheap step only).
     // Measured, 10 000 queries x 10M aa subjects, best hit, per step (tools/bound_probe.py, profiles/
-    // r02_bound_probe.txt): bound 5 2.1 ms, 8 7.3 ms, 10 11.4 ms, 12 16.7 ms, no bound 28.6 ms; nucleotides 1.8, 6.3,
-    // 9.7, 13.8, 16.7.
+    // r02_bound_probe.txt): bound 5 2.1 ms, 8 8.1 ms, 12 9.2 ms, 14 14.3 ms, no bound 28 ms; nucleotides 1.8, 6.6, 7.7,
+    // 10.4, 16.7.
     const uint32_t k_mode = max_num_hits == SMAFA_NONE ? 0u : max_num_hits;
     const uint32_t cols = std::min<uint32_t>(32u, db->L);
     // first step: level 1 looks at `cols` columns of one plane; at a bound of a sixth of them it still rejects all but
     // a few percent of the (wave, query) steps
-    std::vector<uint32_t> ladder = {(cols - 1u) / 6u, 5u * cols / 16u};
+    std::vector<uint32_t> ladder = {(cols - 1u) / 6u, 3u * cols / 8u};
     const uint32_t limit = std::min<uint32_t>(max_div, db->L);
     std::vector<smafa_hit> done;      // rows of the finished queries (the caller's query numbers), ordered
     std::vector<uint32_t> ids;        // open queries: position in the current batch -> the caller's number (empty: same)

@@ -57,7 +57,10 @@ __host__ __device__ constexpr int scan_min_waves(int ps, int w, int t) {
 #define SMAFA_CASCADE 1  // 1: a one-word first-level bound in front of the folded bound (+7 % aa, +4 % nt measured)
 #endif
 #ifndef SMAFA_AND_PAIR
-#define SMAFA_AND_PAIR 1  // 1: the prefilter bounds two subjects with one popcount (weaker, cheaper: +5 % measured)
+#define SMAFA_AND_PAIR 0  // 1: the folded bound takes two subjects per popcount (popcount(a & b) <= both).  +5 % in round 1 at
+                          // bound 5; nothing today at tight bounds (the zone level runs in front), and at bounds 9-13 it
+                          // lets every query through where the per-subject fold still rejects them: scan_kernel, 10 000
+                          // queries x 10M aa, bound 10: 28.7 -> 8.4 ms (profiles/r02_bound_probe.txt)
 #endif
 
 __host__ __device__ constexpr int round_up4(int x) { return (x + 3) & ~3; }

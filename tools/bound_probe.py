@@ -11,12 +11,13 @@ from smafa_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 alphabet = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 nq = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000
-subj = synth.subjects(n, 60, alphabet, seed=1 if alphabet else 2)
+L = int(sys.argv[4]) if len(sys.argv) > 4 else 60
+subj = synth.subjects(n, L, alphabet, seed=1 if alphabet else 2)
 q, _, _ = synth.queries(subj, nq, alphabet, seed=3, max_subs=10 if alphabet else 6)
 for env in ({}, {"SMAFA_ZONE": "2"}, {"SMAFA_ZONE": "0"}, {"SMAFA_ZONE": "0", "SMAFA_PRUNE_P": "1"}, {"SMAFA_ZONE": "2", "SMAFA_PRUNE_P": "1"}):
     for k in ("SMAFA_ZONE", "SMAFA_PRUNE_P"): os.environ.pop(k, None)
     os.environ.update(env)
-    store = smafa_amd.SubjectStore(60, alphabet); store.push(subj)
+    store = smafa_amd.SubjectStore(L, alphabet); store.push(subj)
     qs = smafa_amd.QuerySet(store, q)
     hits = torch.empty(3 * (1 << 24), dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
     for k in (None, 1):
