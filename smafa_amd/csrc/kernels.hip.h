@@ -56,6 +56,9 @@ __host__ __device__ constexpr int scan_min_waves(int ps, int w, int t) {
 #ifndef SMAFA_CASCADE
 #define SMAFA_CASCADE 1  // 1: a one-word first-level bound in front of the folded bound (+7 % aa, +4 % nt measured)
 #endif
+#ifndef SMAFA_SUM_FOLD
+#define SMAFA_SUM_FOLD 1  // scan_kernel<.., SUMF = true> for two-word launches with a bound of 13..17 (engine.hip launch_scan_t)
+#endif
 #ifndef SMAFA_AND_PAIR
 #define SMAFA_AND_PAIR 0  // 1: the folded bound takes two subjects per popcount (popcount(a & b) <= both).  +5 % in round 1 at
                           // bound 5; nothing today at tight bounds (the zone level runs in front), and at bounds 9-13 it
@@ -259,7 +262,7 @@ __device__ __forceinline__ void finish_rows(const ScanArgs &a) {
 // store: subjects carry code bits 0-1, queries still carry the N bit, which mismatches every subject).
 // T = wave tiles per wave: a lane owns 4*T subjects, so the per-query OR / compare / branch / LDS read are
 // shared by 4*T pairs.  T = 2 where the registers allow it without losing occupancy.
-template <int PS, int PQ, int W, int T, bool SEED>
+template <int PS, int PQ, int W, int T, bool SEED, bool SUMF>
 __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(const uint4 *__restrict__ planes,
                                                                              const uint32_t *__restrict__ qrec,
                                                                              ScanArgs a) {
@@ -447,6 +450,23 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
                                 // popcount(a & b) <= min(popcount a, popcount b): one popcount bounds two subjects
                                 const uint32_t t0 = __builtin_popcount(m0 & m1) + nu, t2 = __builtin_popcount(m2 & m3) + nu;
                                 any = t ? or3(any, t0, t2) : (t0 | t2);
+                            } else if (SUMF) {
+                                // SUMF (launches whose bound is 13..17 at two words): the filter plane's own distance,
+                                // one popcount per word chained through v_bcnt's accumulator.  The OR-fold above lays
+                                // column j on column j + 32: its popcount is ~24 of 32 for unrelated sequences at W = 2 —
+                                // it stops rejecting at 13 (bound 14: 25.3 ms vs 11.7 this way, 10 000 queries x 10M aa)
+                                // — and ~30 from W = 3 on, where it rejects up to a bound of ~24 and is the cheaper test.
+                                // Chosen per launch: a per-query branch in this loop cost 30 % at bounds 8-12.
+                                uint32_t t0 = nu, t1 = nu, t2 = nu, t3 = nu;
+#pragma unroll
+                                for (int w = 0; w < W; w++) {
+                                    const uint32_t qv = qw[qslot(PQ, W, FP, w)];
+                                    t0 += __builtin_popcount(s[t][FP * W + w].x ^ qv);
+                                    t1 += __builtin_popcount(s[t][FP * W + w].y ^ qv);
+                                    t2 += __builtin_popcount(s[t][FP * W + w].z ^ qv);
+                                    t3 += __builtin_popcount(s[t][FP * W + w].w ^ qv);
+                                }
+                                any = t ? or3(or3(t0, t1, t2), t3, any) : (or3(t0, t1, t2) | t3);
                             } else {
                                 const uint32_t t0 = __builtin_popcount(m0) + nu, t1 = __builtin_popcount(m1) + nu;
                                 const uint32_t t2 = __builtin_popcount(m2) + nu, t3 = __builtin_popcount(m3) + nu;
