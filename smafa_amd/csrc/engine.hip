@@ -524,7 +524,10 @@ static double zone_pass_share(const smafa_db *db, uint32_t thr0) {
 static bool zone_pays(const smafa_db *db, uint32_t thr0, bool prunes) {
     if (!db->lazy || !db->use_filter) return false;
     if (db->zone != 1) return db->zone == 2;
-    return zone_pass_share(db, thr0) < (prunes ? 0.6 : db->zone_loose);
+    // (five planes of four words: the survivors' levels 2-3 fetch 20 vectors per tile from L2 — the crossover comes
+    // earlier: aa 128 columns at bound 7, share 0.5: 11.7 ms vs 9.5 ms without the zone level; 80 columns: 6.6 vs 7.8)
+    const double pays = db->W <= 4 && db->P * db->W >= 20 ? 0.4 : 0.6;  // (scan_wide_kernel's own zone level: 0.6)
+    return zone_pass_share(db, thr0) < (prunes ? pays : db->zone_loose);
 }
 // up to 128 columns: scan_zone_kernel; longer: the zone level inside scan_wide_kernel (ScanArgs::zone_on)
 static bool use_zone(const smafa_db *db, uint32_t thr0, bool prunes) { return db->W <= 4 && zone_pays(db, thr0, prunes); }
