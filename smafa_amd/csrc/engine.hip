@@ -435,17 +435,25 @@ template <int PS, int PQ, int W, int T>
 static void launch_scan_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
     // the seed pass of the running-minimum mode (no append) has its own instantiation
     const bool seed = a.hits == nullptr && a.k_tight == 1;
-    // two words per plane, bound 13..17: level 2 sums the filter plane's per-word popcounts (scan_kernel, SUMF) — the
-    // OR-fold rejects nothing there, and beyond 17 neither does
-    const bool sumf = SMAFA_SUM_FOLD && W == 2 && !seed && a.use_filter && a.thr0 > 12u && a.thr0 <= 17u;
-    note_kernel(db, "smafa::scan_kernel<%d, %d, %d, %d, %s, %s>", PS, PQ, W, T, seed ? "true" : "false", sumf ? "true" : "false");
+    // Two words per plane: level 2 by the bound of the launch.  Up to 12 the OR-fold of the filter plane's words (one
+    // popcount per subject); 13..17 the filter plane's per-word popcounts summed (FOLD 1: the OR-fold rejects nothing
+    // there); 18..32, stores of 3 planes and more, the same over two planes (FOLD 2: flat 14.7 ms from 18 to 28 where the full
+    // comparison costs 31, 10 000 queries x 10M aa); beyond that nothing rejects.
+    int fold = 0;
+    if (SMAFA_SUM_FOLD && W == 2 && !seed && a.use_filter) {
+        if (a.thr0 > 12u && a.thr0 <= 17u) fold = 1;
+        else if (PS >= 3 && a.thr0 >= 18u && a.thr0 <= 32u) fold = 2;
+    }
+    note_kernel(db, "smafa::scan_kernel<%d, %d, %d, %d, %s, %d>", PS, PQ, W, T, seed ? "true" : "false", fold);
     const uint4 *planes = reinterpret_cast<const uint4 *>(db->d_planes);
     if (seed)
-        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, true, false>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
-    else if (W == 2 && sumf)
-        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, false, (W == 2)>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
+        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, true, 0>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
+    else if (W == 2 && fold == 1)
+        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, false, (W == 2 ? 1 : 0)>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
+    else if (W == 2 && PS >= 3 && fold == 2)
+        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, false, (W == 2 && PS >= 3 ? 2 : 0)>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
     else
-        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, false, false>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
+        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, false, 0>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
 }
 
 // wave tiles per wave (4*T subjects per lane).  With the cheap first-level bound the per-query work that does
@@ -945,8 +953,8 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
     // default): the scan would run the all-planes kernel until each query's running bound has tightened.  Most queries
     // of real inputs have their k nearest subjects within a few mismatches, so first ask the cheap questions: a LADDER of
     // scans whose bound starts at a value the prefilters still handle well (5 of the first 32 columns: level 1 prunes,
-    // zone kernel; then 12, and 16 at two words per plane: the folded bounds of the all-planes kernel still reject nearly
-    // every pair there), each over the queries the step before left open.  A query with at least k rows within a step's bound is
+    // zone kernel; then 12, and 30 (two planes: 16) at two words per plane: the folded bounds of the all-planes kernel still reject
+    // nearly every pair there), each over the queries the step before left open.  A query with at least k rows within a step's bound is
     // finished: its k-th smallest distance is <= that bound, so every row it may print is among them.  Whoever is
     // left takes the tightening path, as a compacted batch.  Exact at every step.  A step that finishes fewer than an
     // eighth of its queries is the last one (data without near neighbours pays for one cheap step only).
@@ -958,7 +966,11 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
     // first step: level 1 looks at `cols` columns of one plane; at a bound of a sixth of them it still rejects all but
     // a few percent of the (wave, query) steps
     std::vector<uint32_t> ladder = {(cols - 1u) / 6u, 3u * cols / 8u};
-    if (db->W == 2 && db->L >= 33) ladder.push_back(16u);  // two words: scan_kernel's SUMF form still rejects at 13..17
+    if (db->W == 2 && db->L >= 33) {  // two words: scan_kernel's FOLD 1 / FOLD 2 forms still reject at 13..17 / 18..32
+        // (a step at 16 in front of the one at 30 costs nearly as much and is redundant: queries 0..30 substitutions away
+        // from their subject, 10 000 x 10M aa: 35 ms with both, profiles/r02_besthit_ladder.txt)
+        ladder.push_back(db->P >= 3 ? 30u : 16u);
+    }
     const uint32_t limit = std::min<uint32_t>(max_div, db->L);
     std::vector<smafa_hit> done;      // rows of the finished queries (the caller's query numbers), ordered
     std::vector<uint32_t> ids;        // open queries: position in the current batch -> the caller's number (empty: same)
@@ -1006,7 +1018,8 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
             }
         merge_done(fin);
         log_line(2, "near-hit step at bound %u finished %u of %u queries", bound, cur_n - (uint32_t)open.size(), cur_n);
-        const bool paid = (uint64_t)(cur_n - open.size()) * 8u >= cur_n;
+        // (the step at 30 costs half of what the loose path costs: it is taken only after a step that finished a quarter)
+        const bool paid = (uint64_t)(cur_n - open.size()) * (step + 1 < ladder.size() && ladder[step + 1] >= 30u ? 4u : 8u) >= cur_n;
         std::vector<uint32_t> next_ids(open.size());
         std::vector<uint8_t> next_codes(open.size() * (size_t)db->L);
         for (size_t i = 0; i < open.size(); i++) {

@@ -57,7 +57,7 @@ __host__ __device__ constexpr int scan_min_waves(int ps, int w, int t) {
 #define SMAFA_CASCADE 1  // 1: a one-word first-level bound in front of the folded bound (+7 % aa, +4 % nt measured)
 #endif
 #ifndef SMAFA_SUM_FOLD
-#define SMAFA_SUM_FOLD 1  // scan_kernel<.., SUMF = true> for two-word launches with a bound of 13..17 (engine.hip launch_scan_t)
+#define SMAFA_SUM_FOLD 1  // scan_kernel<.., FOLD = 1 | 2> for two-word launches with a bound of 13..17 | 18..32 (engine.hip launch_scan_t)
 #endif
 #ifndef SMAFA_AND_PAIR
 #define SMAFA_AND_PAIR 0  // 1: the folded bound takes two subjects per popcount (popcount(a & b) <= both).  +5 % in round 1 at
@@ -262,7 +262,7 @@ __device__ __forceinline__ void finish_rows(const ScanArgs &a) {
 // store: subjects carry code bits 0-1, queries still carry the N bit, which mismatches every subject).
 // T = wave tiles per wave: a lane owns 4*T subjects, so the per-query OR / compare / branch / LDS read are
 // shared by 4*T pairs.  T = 2 where the registers allow it without losing occupancy.
-template <int PS, int PQ, int W, int T, bool SEED, bool SUMF>
+template <int PS, int PQ, int W, int T, bool SEED, int FOLD>
 __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(const uint4 *__restrict__ planes,
                                                                              const uint32_t *__restrict__ qrec,
                                                                              ScanArgs a) {
@@ -412,7 +412,9 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
                 const bool l1 = __builtin_amdgcn_readfirstlane((int)level1_on) != 0;
                 for (uint32_t i = 0; i < nqc; i++, rec += RV) {
                     uint32_t qw[RS];
-                    read_record(rec, qw, 0, HV);  // fast path: filter-plane words + bound slot only
+                    // fast path: filter-plane words + bound slot only (FOLD 2: the next plane's words as well)
+                    constexpr int HV2 = FOLD == 2 ? (qslot(PQ, W, filter_plane(PQ) == 0 ? 1 : 0, W - 1) + 4) / 4 : HV;
+                    read_record(rec, qw, 0, HV2 > HV ? HV2 : HV);
                     const uint32_t nu = qw[BS];
                     uint32_t any = 0;
                     bool go = true;  // wave-uniform: does this query reach the folded bound?
@@ -450,8 +452,24 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
                                 // popcount(a & b) <= min(popcount a, popcount b): one popcount bounds two subjects
                                 const uint32_t t0 = __builtin_popcount(m0 & m1) + nu, t2 = __builtin_popcount(m2 & m3) + nu;
                                 any = t ? or3(any, t0, t2) : (t0 | t2);
-                            } else if (SUMF) {
-                                // SUMF (launches whose bound is 13..17 at two words): the filter plane's own distance,
+                            } else if (FOLD == 2) {
+                                // FOLD 2 (launches whose bound is 18..32 at two words, 3 planes and more): the distance
+                                // over TWO planes, word by word — a column whose letters differ shows in the filter
+                                // plane or in the next one three times out of four (~45 of 60 columns for unrelated
+                                // sequences), for half the instructions of the full comparison
+                                constexpr int FP2 = FP == 0 ? 1 : 0;
+                                uint32_t t0 = nu, t1 = nu, t2 = nu, t3 = nu;
+#pragma unroll
+                                for (int w = 0; w < W; w++) {
+                                    const uint32_t qa = qw[qslot(PQ, W, FP, w)], qb = qw[qslot(PQ, W, FP2, w)];
+                                    t0 += __builtin_popcount(or_xor(s[t][FP * W + w].x ^ qa, s[t][FP2 * W + w].x, qb));
+                                    t1 += __builtin_popcount(or_xor(s[t][FP * W + w].y ^ qa, s[t][FP2 * W + w].y, qb));
+                                    t2 += __builtin_popcount(or_xor(s[t][FP * W + w].z ^ qa, s[t][FP2 * W + w].z, qb));
+                                    t3 += __builtin_popcount(or_xor(s[t][FP * W + w].w ^ qa, s[t][FP2 * W + w].w, qb));
+                                }
+                                any = t ? or3(or3(t0, t1, t2), t3, any) : (or3(t0, t1, t2) | t3);
+                            } else if (FOLD == 1) {
+                                // FOLD 1 (launches whose bound is 13..17 at two words): the filter plane's own distance,
                                 // one popcount per word chained through v_bcnt's accumulator.  The OR-fold above lays
                                 // column j on column j + 32: its popcount is ~24 of 32 for unrelated sequences at W = 2 —
                                 // it stops rejecting at 13 (bound 14: 25.3 ms vs 11.7 this way, 10 000 queries x 10M aa)
@@ -476,7 +494,7 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
                         // sign bit set <=> some lower bound <= bound
                         if (__ballot((int32_t)any < 0) != 0ull) {  // wave-uniform branch, rare
                             passes++;
-                            read_record(rec, qw, HV, RV);
+                            read_record(rec, qw, 0, RV);
                             full_compare(qw, qc + i);
                         }
                     }

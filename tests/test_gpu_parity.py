@@ -192,7 +192,7 @@ def test_kth_bound_modes(k, max_div):
 
 @pytest.mark.parametrize("alphabet,n_letters", [(0, 4), (1, 20)])
 def test_near_hit_probe_boundaries(alphabet, n_letters):
-    """k-th-distance modes with a loose or absent bound: a ladder of bounded scans (bounds 5, 12, 16 at L = 60) finishes
+    """k-th-distance modes with a loose or absent bound: a ladder of bounded scans (bounds 5, 12, then 30 — 16 for a 2-plane store — at L = 60) finishes
     the queries with at least k rows within a step's bound, the rest take the tightening path as a compacted batch;
     queries sit exactly on both sides of every boundary, with ties"""
     rng = np.random.default_rng(31 + alphabet)
@@ -200,7 +200,7 @@ def test_near_hit_probe_boundaries(alphabet, n_letters):
     s = rng.integers(0, n_letters, size=(n, L), dtype=np.uint8)
     s[5000:5003] = s[17]              # 4 copies of row 17 in all: ties at distance 0 ...
     qs = []
-    for subs in (0, 1, 4, 5, 5, 6, 6, 7, 9, 11, 12, 12, 13, 13, 15, 16, 16, 17, 17, 30):  # ... queries at 0..30 substitutions from their subject
+    for subs in (0, 1, 4, 5, 5, 6, 6, 7, 9, 11, 12, 12, 13, 13, 15, 16, 16, 17, 17, 18, 24, 29, 30, 30, 31, 32, 33, 36):  # 0..36 substitutions
         for base in (17, 400, 4242, 19999):
             r = s[base].copy()
             cols = rng.choice(L, size=subs, replace=False)
@@ -210,7 +210,7 @@ def test_near_hit_probe_boundaries(alphabet, n_letters):
     q = np.array(qs, dtype=np.uint8)
     store = smafa_amd.SubjectStore(L, alphabet)
     store.push(s)
-    for D in (None, 6, 12, 13, 16, 17, 18, 20):  # 13..17: the all-planes kernel's per-word level 2 (SUMF)
+    for D in (None, 6, 12, 13, 16, 17, 18, 20, 24, 30, 32, 33, 35):  # 13..17 / 18..32: the all-planes kernel's FOLD 1 / FOLD 2 forms
         full = oracle.scan_codes(s, q, L if D is None else D)
         if D is not None:
             assert store.scan(q, max_divergence=D).tobytes() == full.tobytes(), D

@@ -7,10 +7,11 @@ import smafa_amd
 from smafa_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 alphabet = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+max_subs = int(sys.argv[3]) if len(sys.argv) > 3 else (10 if alphabet else 6)  # substitutions per query: 0..max_subs
 subj = synth.subjects(n, 60, alphabet, seed=1 if alphabet else 2)
 store = smafa_amd.SubjectStore(60, alphabet); store.push(subj)
 for nq in (2000, 10_000, 100_000):
-    q, _, _ = synth.queries(subj, nq, alphabet, seed=3, max_subs=10 if alphabet else 6)
+    q, _, _ = synth.queries(subj, nq, alphabet, seed=3, max_subs=max_subs)
     store.scan(q[:8], max_divergence=None, max_num_hits=1)
     for D in (None, 5 if alphabet else 3):
         best = None

@@ -22,7 +22,7 @@ for env in ({}, {"SMAFA_ZONE": "2"}, {"SMAFA_ZONE": "0"}, {"SMAFA_ZONE": "0", "S
     hits = torch.empty(3 * (1 << 24), dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
     for k in (None, 1):
         line = []
-        for D in (5, 6, 7, 8, 9, 10, 12, 14, 16, 18):
+        for D in (5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 24, 28, 30, 34):
             best = 1e9
             for rep in range(3):
                 store.scan_launch(qs, D, k, hits.data_ptr(), 1 << 24, cnt.data_ptr()); store.sync()
