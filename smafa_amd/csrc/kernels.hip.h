@@ -36,6 +36,7 @@
 // reservation per 64-query chunk (RowStage, emit, flush_rows, finish_rows).
 #pragma once
 
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -55,6 +56,11 @@ __host__ __device__ constexpr int scan_min_waves(int ps, int w, int t) {
 }
 #ifndef SMAFA_CASCADE
 #define SMAFA_CASCADE 1  // 1: a one-word first-level bound in front of the folded bound (+7 % aa, +4 % nt measured)
+#endif
+#ifndef SMAFA_WIDE_AND_PAIR
+#define SMAFA_WIDE_AND_PAIR 1  // scan_wide_kernel keeps the two-subjects-per-popcount form of level 2: it only runs at bounds
+                               // level 1 prunes at, where the form is the cheaper one (one-word stores, 10M x 20 aa, bound 3:
+                               // 7.1 ms vs 8.6 ms per subject — profiles/r02_short_check.txt)
 #endif
 #ifndef SMAFA_SUM_FOLD
 #define SMAFA_SUM_FOLD 1  // scan_kernel<.., FOLD = 1 | 2> for two-word launches with a bound of 13..17 | 18..32 (engine.hip launch_scan_t)
@@ -1524,13 +1530,12 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
                     todo |= zq[t];
                 }
             }
-            while (probe && todo != 0ull) {
-                const uint32_t i = (uint32_t)__builtin_ctzll(todo);
-                todo &= todo - 1ull;
+            // one query of the chunk against the wave's T tiles; GATED: only the tile slots in `tiles` (the zone level's
+            // survivors) — the ungated form keeps the four tiles' level 1 free of branches (a gated loop for every store
+            // cost the unsorted ones 20 %: one-word stores, 10M x 20 aa, bound 3: 7.1 -> 8.5 ms)
+            auto step = [&](uint32_t i, uint32_t tiles, auto gated_tag) {
+                constexpr bool GATED = decltype(gated_tag)::value;
                 const uint32_t *rec = rec0 + i * RS;
-                uint32_t tiles = 0;  // the tile slots this query still has to look at
-#pragma unroll
-                for (int t = 0; t < T; t++) tiles |= (uint32_t)((zq[t] >> i) & 1ull) << t;
                 uint32_t live = 0;
                 {
                     const uint4 head = heads[buf][i][0];  // one LDS read at a constant stride
@@ -1540,16 +1545,16 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
                         uint32_t any1 = 0;
 #pragma unroll
                         for (int t = 0; t < T; t++) {
-                            if (!((tiles >> t) & 1u)) continue;
+                            if (GATED && !((tiles >> t) & 1u)) continue;
                             const uint32_t u0 = __builtin_popcount(f[t][0].x ^ qw0) + nu;
                             const uint32_t u1 = __builtin_popcount(f[t][0].y ^ qw0) + nu;
                             const uint32_t u2 = __builtin_popcount(f[t][0].z ^ qw0) + nu;
                             const uint32_t u3 = __builtin_popcount(f[t][0].w ^ qw0) + nu;
-                            any1 = or3(or3(u0, u1, u2), u3, any1);
+                            any1 = (!GATED && t == 0) ? (or3(u0, u1, u2) | u3) : or3(or3(u0, u1, u2), u3, any1);
                         }
                         const bool go = __ballot((int32_t)any1 < 0) != 0ull;
                         level1_passes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(level1_passes + (go ? 1u : 0u)));
-                        if (!go) continue;
+                        if (!go) return;
                     }
                     // level 2: the resident words folded, two subjects per popcount
                     uint32_t qf[NF];
@@ -1559,7 +1564,7 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
                     if (NF >= 4) qf[3] = heads[buf][i][HV - 1].x;
 #pragma unroll
                     for (int t = 0; t < T; t++) {
-                        if (!((tiles >> t) & 1u)) continue;
+                        if (GATED && !((tiles >> t) & 1u)) continue;
                         uint32_t m0 = f[t][0].x ^ qf[0], m1 = f[t][0].y ^ qf[0];
                         uint32_t m2 = f[t][0].z ^ qf[0], m3 = f[t][0].w ^ qf[0];
 #pragma unroll
@@ -1570,14 +1575,14 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
                             m3 = or_xor(m3, f[t][w].w, qf[w]);
                         }
                         const uint32_t sign =
-                            SMAFA_AND_PAIR ? ((__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu))
+                            SMAFA_WIDE_AND_PAIR ? ((__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu))
                                            : (or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
                                                   __builtin_popcount(m2) + nu) |
                                               (__builtin_popcount(m3) + nu));
                         if (__ballot((int32_t)sign < 0) != 0ull) live |= 1u << t;
                     }
                     live = (uint32_t)__builtin_amdgcn_readfirstlane((int)live);
-                    if (SMAFA_AND_PAIR && live != 0) {  // subjects one by one before a tile is streamed (see scan_lazy_kernel)
+                    if (SMAFA_WIDE_AND_PAIR && live != 0) {  // subjects one by one before a tile is streamed (see scan_lazy_kernel)
 #pragma unroll
                         for (int t = 0; t < T; t++) {
                             if ((live >> t) & 1u) {
@@ -1598,7 +1603,7 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
                         }
                         live = (uint32_t)__builtin_amdgcn_readfirstlane((int)live);
                     }
-                    if (live == 0) continue;
+                    if (live == 0) return;
                     passes++;
                 }
                 while (live) {  // level 3: exact, tile by tile — ONE copy of the comparison code
@@ -1606,6 +1611,18 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
                     live &= live - 1;
                     if (tile0 + t < a.tile_end) wide_compare(tile0 + t, rec, qc + i);
                 }
+            };
+            if (probe && zone_on) {
+                while (todo != 0ull) {
+                    const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    uint32_t tiles = 0;  // the tile slots this query still has to look at
+#pragma unroll
+                    for (int t = 0; t < T; t++) tiles |= (uint32_t)((zq[t] >> i) & 1ull) << t;
+                    step(i, tiles, std::true_type{});
+                }
+            } else if (probe) {
+                for (uint32_t i = 0; i < nqc; i++) step(i, (1u << T) - 1u, std::false_type{});
             }
             if (probe) {
                 passes = (uint32_t)__builtin_amdgcn_readfirstlane((int)passes);
