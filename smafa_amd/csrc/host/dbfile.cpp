@@ -126,10 +126,20 @@ int smafa_dbfile_write(const char *path, int alphabet, const uint8_t *codes, uin
         auto encode_rows = [&](unsigned t) {
             const uint64_t lo = n * t / n_threads, hi = n * (t + 1) / n_threads;
             std::vector<uint8_t> &out = parts[t];
-            out.reserve((size_t)(hi - lo) * (1 + nw * 9));
+            // written through a raw pointer into a buffer sized for the worst case (10 bytes per varint), cut to size
+            // at the end: a push_back per byte was most of makedb's serialisation time
+            out.resize((size_t)(hi - lo) * (10 + nw * 10));
+            uint8_t *p = out.data();
+            auto put = [&](uint64_t v) {
+                while (v >= 0x80) {
+                    *p++ = (uint8_t)(v | 0x80);
+                    v >>= 7;
+                }
+                *p++ = (uint8_t)v;
+            };
             for (uint64_t j = lo; j < hi; j++) {
                 const uint8_t *row = codes + (size_t)j * seq_len;
-                put_varint(out, nw);
+                put(nw);
                 for (size_t w = 0; w < nw; w++) {
                     uint64_t word = 0;
                     const size_t lim = std::min<size_t>(12, seq_len - w * 12);
@@ -141,9 +151,10 @@ int smafa_dbfile_write(const char *path, int alphabet, const uint8_t *codes, uin
                         }
                         word |= (uint64_t)kOneHotOfCode[c] << (5 * i);
                     }
-                    put_varint(out, word);
+                    put(word);
                 }
             }
+            out.resize((size_t)(p - out.data()));
         };
         if (n_threads > 1) {
             std::vector<std::thread> pool;

@@ -257,8 +257,10 @@ int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet) {
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
     BulkRecords recs;
+    const double t_start = now_seconds();
     int rc = load_records_bulk(subject_fasta, alphabet, false, recs);  // src/lib.rs:143-152
     if (rc) return rc;
+    const double t_parsed = now_seconds();
     if (recs.err_kind == 3) return set_error(SMAFA_ERR_PANIC, "Cannot add empty sequence to WindowSet");  // src/lib.rs:103-108
     if (recs.err_kind == 1) return set_error(SMAFA_ERR_PANIC, "%s", recs.err_msg.c_str());                  // src/lib.rs:38-41
     if (recs.err_kind == 2)  // src/lib.rs:92-101
@@ -271,6 +273,7 @@ int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet) {
     log_line(1, "Encoding of %llu sequences complete, writing db file %s", (unsigned long long)n, db_path);  // src/lib.rs:154-158
     rc = smafa_dbfile_write(db_path, alphabet, codes.data(), n, (uint32_t)L);  // src/lib.rs:161-162
     if (rc == SMAFA_OK) log_line(1, "DB file written");
+    log_line(2, "makedb: parse + encode %.2f s, serialise + write %.2f s", t_parsed - t_start, now_seconds() - t_parsed);
     return rc;
 }
 
