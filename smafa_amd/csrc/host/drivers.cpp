@@ -285,7 +285,9 @@ int smafa_makedb_packed(const char *subject_fasta, const char *db_path, int alph
         return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
     std::thread warm(warm_device, device < 0 ? 1 << 30 : device);  // (an out-of-range device: nothing to warm)
     BulkRecords recs;
+    const double t_start = now_seconds();
     int rc = load_records_bulk(subject_fasta, alphabet, false, recs);  // src/lib.rs:143-152
+    const double t_parsed = now_seconds();
     warm.join();
     if (rc) return rc;
     if (recs.err_kind == 3) return set_error(SMAFA_ERR_PANIC, "Cannot add empty sequence to WindowSet");
@@ -299,14 +301,19 @@ int smafa_makedb_packed(const char *subject_fasta, const char *db_path, int alph
         log_line(1, "Encoding of %llu sequences complete, packing on the host and writing %s", (unsigned long long)recs.n, db_path);
         rc = pack_store_on_host(alphabet, (uint32_t)recs.L, recs.codes.data(), recs.n, db_path);
         if (rc == SMAFA_OK) log_line(1, "DB file written");
+        log_line(2, "makedb --packed: parse + encode %.2f s, pack on the host + write %.2f s", t_parsed - t_start, now_seconds() - t_parsed);
         return rc;
     }
     log_line(1, "Encoding of %llu sequences complete, packing on device %d and writing %s", (unsigned long long)recs.n, device, db_path);
     DbGuard guard;
+    const double t_ready = now_seconds();
     rc = smafa_db_create(&guard.db, device, alphabet, (uint32_t)recs.L);
     if (!rc) rc = smafa_db_append(guard.db, recs.codes.data(), recs.n);
+    const double t_packed = now_seconds();
     if (!rc) rc = smafa_db_save(guard.db, db_path);
     if (rc == SMAFA_OK) log_line(1, "DB file written");
+    log_line(2, "makedb --packed: parse + encode %.2f s (device ready %.2f s after start), pack on the device %.2f s, copy back + write %.2f s",
+             t_parsed - t_start, t_ready - t_start, t_packed - t_ready, now_seconds() - t_packed);
     return rc;
 }
 
