@@ -46,6 +46,7 @@ double now_seconds();
 
 // alphabet tables (host/alphabet.cpp)
 uint8_t code_of(int alphabet, uint8_t byte);  // 255 = outside the alphabet
+const uint8_t *code_table(int alphabet);      // the same as a 256-entry table (for loops over many bytes)
 char letter_of(int alphabet, uint8_t code);
 const char *alphabet_noun(int alphabet);  // "nucleotide" / "amino acid" for the panic text
 

@@ -35,6 +35,8 @@ uint8_t code_of(int alphabet, uint8_t byte) {
     return alphabet == SMAFA_ALPHABET_AA ? tables().aa[byte] : tables().nt[byte];
 }
 
+const uint8_t *code_table(int alphabet) { return alphabet == SMAFA_ALPHABET_AA ? tables().aa : tables().nt; }
+
 char letter_of(int alphabet, uint8_t code) {
     if (alphabet == SMAFA_ALPHABET_AA) return code < 26 ? (char)('A' + code) : code == 26 ? '*' : code == 27 ? '-' : '?';
     return code < 5 ? "ACGTN"[code] : '?';

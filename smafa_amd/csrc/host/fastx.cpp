@@ -266,6 +266,7 @@ void bad_byte(ChunkOut &c, int alphabet, uint8_t byte, const uint8_t *id, size_t
 // input has `total` bytes, of which n are in memory
 void parse_chunk(const uint8_t *d, size_t n, size_t total, bool fastq, int alphabet, bool want_raw, ChunkOut &c) {
     std::vector<uint8_t> seq;
+    const uint8_t *tab = code_table(alphabet);  // (a call per byte was a third of the parse)
     size_t p = c.lo;
     auto line_end = [&](const uint8_t *dd, size_t lim, size_t from) {
         const size_t e = smafa::line_end(dd, lim, from);
@@ -337,15 +338,23 @@ void parse_chunk(const uint8_t *d, size_t n, size_t total, bool fastq, int alpha
         // encode first (src/lib.rs:150,235: from_bytes runs before any length check)
         const size_t base = c.codes.size();
         c.codes.resize(base + slen);
-        for (size_t i = 0; i < slen; i++) {
-            const uint8_t code = code_of(alphabet, s[i]);
-            if (code == 255) {
+        {
+            uint8_t *dst = c.codes.data() + base;
+            uint8_t seen = 0;  // codes are < 32; 255 marks a byte outside the alphabet
+            for (size_t i = 0; i < slen; i++) {
+                const uint8_t code = tab[s[i]];
+                dst[i] = code;
+                seen |= code;
+            }
+            if (seen & 0x80) {
+                size_t i = 0;
+                while (tab[s[i]] != 255) i++;
+                const uint8_t byte = s[i];
                 c.codes.resize(base);
-                bad_byte(c, alphabet, s[i], d + hs, id_len, i);
+                bad_byte(c, alphabet, byte, d + hs, id_len, i);
                 c.end_pos = p;
                 return;
             }
-            c.codes[base + i] = code;
         }
         if (slen != c.L) {
             c.codes.resize(base);
@@ -461,7 +470,8 @@ bool load_parallel(const uint8_t *d, size_t total, Progress &pr, bool fastq, int
             distrust = true;
             return;
         }
-        c.codes.reserve((c.hi - c.lo) / 2);
+        c.codes.reserve(c.hi - c.lo);  // an upper bound: no reallocation while the chunk is parsed
+        if (want_raw) c.raw.reserve(c.hi - c.lo);
         parse_chunk(d, std::min(have, total), total, fastq, alphabet, want_raw, c);
         if (c.truncated) {  // a record longer than the slack: once more with everything there
             const size_t lo = c.lo, hi = c.hi;
