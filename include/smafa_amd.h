@@ -44,6 +44,7 @@ extern "C" {
 
 typedef struct smafa_db smafa_db;     /* subject store resident in HBM — WindowSet, src/lib.rs:54-60 */
 typedef struct smafa_qset smafa_qset; /* a packed query batch resident in HBM */
+typedef struct smafa_group smafa_group; /* one subject store replicated over several GPUs of a node */
 
 /* one scan result row: the (query_number, i, distance) of src/lib.rs:292 / :310 */
 typedef struct {
@@ -146,10 +147,22 @@ void smafa_qset_destroy(smafa_qset *qs);
  */
 int smafa_scan_launch(smafa_db *db, smafa_qset *qs, uint32_t max_div, uint32_t max_num_hits, void *d_hits,
                       uint64_t cap, void *d_count);
+/* One store pass PER QUERY of a resident set — north_star's literal "each query is broadcast against all subjects" — all
+ * enqueued back to back by this one call (no host round trip between passes): query i's rows go to
+ * d_hits + i * cap_per_query (rows), its exact count to the i-th uint64 of d_counts.  Each pass is the one-launch
+ * fixed-bound scan smafa_scan_launch runs for a one-query set; with the zone level off (smafa_set_zone_level 0) it
+ * streams the prefilter's whole bit-plane: the HBM-bound form bench.py's `stream` leg times.  use_graph != 0: the passes
+ * are captured once as a HIP graph and replayed while the arguments stay the same.  Replaces the same loop as
+ * smafa_scan_launch (src/lib.rs:232-318 around get_distances, :238), one query per iteration as the reference runs it. */
+int smafa_scan_each(smafa_db *db, smafa_qset *qs, uint32_t max_div, void *d_hits, uint64_t cap_per_query, void *d_counts,
+                    int use_graph);
 int smafa_sync(smafa_db *db);
 /* Device time in ms of the scan kernel(s) of the most recent smafa_scan_launch / smafa_scan_hits on
  * this handle, from HIP events recorded on the launch stream; also how many kernel launches it took. */
 int smafa_last_scan_ms(smafa_db *db, float *ms, uint32_t *n_launches);
+/* Totals over the most recent smafa_scan_hits call on this handle (a best-hit or k-th call without a tight bound is
+ * several scans: the near-hit ladder, then the tightening path): device time of the scan kernels, kernel launches, scans. */
+int smafa_last_call_stats(smafa_db *db, float *kernel_ms, uint32_t *n_launches, uint32_t *n_scans);
 /* How the most recent scan kernel launch on this handle was laid out: whether it kept only the prefilter's plane
  * of each subject resident (then a sparse-hit scan streams words_per_plane*4 bytes per subject instead of
  * bytes_per_subject), wave tiles per wave, and query blocks (= passes over the store). */
@@ -167,6 +180,28 @@ int smafa_set_prefilter(smafa_db *db, int enabled);
  * pass streams the prefilter's plane: the HBM-bound form), 2 = whenever the filter-plane-resident kernel runs.  Results
  * are identical in every mode. */
 int smafa_set_zone_level(smafa_db *db, int mode);
+
+/* ------------------------------------------------- the same store on several GPUs */
+/*
+ * "queries sharded across the handle's devices internally".  A group is ONE subject store replicated on every
+ * entry of `devices` (an entry may repeat: several handles on one GPU); what is sharded is the reference's per-query loop,
+ * src/lib.rs:232-318, around get_distances (:238) — it carries no state between queries but the running query number.
+ * smafa_group_scan_hits has the contract of smafa_scan_hits (same bounds, same order, same grow-and-retry): the batch
+ * is cut into ndev contiguous blocks, block g is scanned on devices[g] by its own host thread, and the blocks' rows are
+ * concatenated in block order, so the rows do not depend on ndev.  No collective: replicas never exchange anything.
+ * One group = one owner thread at a time.  smafa_query_multi is a caller of this.
+ */
+int smafa_group_create(smafa_group **out, const int *devices, int ndev, int alphabet, uint32_t seq_len);
+/* every member from the same packed store file (smafa_db_load per device; the file is mapped once) */
+int smafa_group_load(smafa_group **out, const int *devices, int ndev, const char *path);
+/* push_encoding x n on every replica (src/lib.rs:91-111); subject indices agree across the members */
+int smafa_group_append(smafa_group *grp, const uint8_t *codes, uint64_t n);
+int smafa_group_scan_hits(smafa_group *grp, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div,
+                          uint32_t max_num_hits, smafa_hit *out, uint64_t cap, uint64_t *n_out);
+int smafa_group_size(const smafa_group *grp);
+/* member `index` (borrowed; owned by the group): for smafa_db_info, the tuning knobs, or device-resident launches */
+smafa_db *smafa_group_member(smafa_group *grp, int index);
+void smafa_group_destroy(smafa_group *grp); /* NULL-safe */
 
 /* -------------------------------------------------------- host-side selection */
 /*

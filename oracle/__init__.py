@@ -29,10 +29,15 @@ ALPHABET_AA = 1
 HIT_DTYPE = np.dtype([("query", "<u4"), ("subject", "<u4"), ("dist", "<u4")])
 
 
+_made = False
+
+
 def build(force: bool = False) -> None:
     """Compile the C restatement (gcc; seconds)."""
-    if force or not os.path.exists(os.path.join(BUILD_DIR, "liboracle.so")) or not os.path.exists(CLI):
+    global _made
+    if force or not _made:  # make decides by file times: a stale build never outlives an edit of the sources
         subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True, capture_output=True)
+        _made = True
 
 
 _libs: dict[str, C.CDLL] = {}

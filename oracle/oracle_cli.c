@@ -87,6 +87,10 @@ int main(int argc, char **argv) {
         return usage();
     }
     fflush(stdout);
+    if (rc == ORC_ERR_RESULT) { /* main returned Err: "Error: .." on stderr, exit status 1 */
+        fprintf(stderr, "Error: %s\n", orc_last_error());
+        return 1;
+    }
     if (rc) {
         fprintf(stderr, "%s\n", orc_last_error());
         return 101; /* a Rust panic exits with 101 */

@@ -491,11 +491,15 @@ int orc_makedb(const char *subject_fasta, const char *db_path) {
         size_t len;
         rc = orc_db_serialize(&ws, &buf, &len);
         if (!rc) {
-            FILE *f = fopen(db_path, "wb");
+            FILE *f = fopen(db_path, "wb"); /* File::create(db_path)? and write_all(..)?, :161-162: an Err, not a panic */
             if (!f) {
-                rc = fail("%s: %s", db_path, strerror(errno));
+                fail("%s: %s", db_path, strerror(errno));
+                rc = ORC_ERR_RESULT;
             } else {
-                if (fwrite(buf, 1, len, f) != len) rc = fail("%s: write error", db_path);
+                if (fwrite(buf, 1, len, f) != len) {
+                    fail("%s: write error", db_path);
+                    rc = ORC_ERR_RESULT;
+                }
                 fclose(f);
             }
             free(buf);
@@ -603,16 +607,16 @@ int orc_query(const char *db_path, const char *query_fasta, int64_t max_divergen
               int64_t limit_per_sequence, FILE *out) {
     uint8_t *buf;
     size_t len;
-    if (slurp(db_path, &buf, &len)) return -1; /* File::open(db_path)? */
+    if (slurp(db_path, &buf, &len)) return ORC_ERR_RESULT; /* File::open(db_path)? / read_to_end(..)?, :208-210 */
     if (len < 4) {                              /* &buffer[0..4], :214 */
         free(buf);
         return fail("range end index 4 out of range for slice of length %zu", len);
     }
     size_t pos = 0;
     uint64_t version;
-    if (rd_varint(buf, 4, &pos, 5, &version)) {
+    if (rd_varint(buf, 4, &pos, 5, &version)) { /* postcard::from_bytes(&buffer[0..4])?, :214 */
         free(buf);
-        return -1;
+        return ORC_ERR_RESULT;
     }
     if (version != ORC_DB_VERSION) { /* :215-217 */
         free(buf);
@@ -621,12 +625,12 @@ int orc_query(const char *db_path, const char *query_fasta, int64_t max_divergen
                     (unsigned)version, ORC_DB_VERSION);
     }
     orc_windowset ws;
-    if (orc_db_deserialize(buf, len, &ws)) {
+    if (orc_db_deserialize(buf, len, &ws)) { /* postcard::from_bytes(&buffer)?, :218 */
         free(buf);
-        return -1;
+        return ORC_ERR_RESULT;
     }
     free(buf);
-    orc_fastx *r = orc_fastx_open(query_fasta);
+    orc_fastx *r = orc_fastx_open(query_fasta); /* .expect("valid path/file of query fasta"), :221 */
     if (!r) {
         orc_ws_free(&ws);
         return -1;
@@ -815,7 +819,7 @@ int orc_count(const char *const *paths, size_t n_paths, FILE *out) {
         orc_fastx *r = orc_fastx_open(paths[i]);
         if (!r) {
             free(b.p);
-            return -1;
+            return ORC_ERR_RESULT; /* `?`, src/lib.rs:381,385 */
         }
         size_t reads = 0, bases = 0;
         for (;;) {
@@ -825,7 +829,7 @@ int orc_count(const char *const *paths, size_t n_paths, FILE *out) {
             if (got < 0) {
                 orc_fastx_close(r);
                 free(b.p);
-                return -1;
+                return ORC_ERR_RESULT; /* `?`, src/lib.rs:381,385 */
             }
             if (!got) break;
             reads++;

@@ -35,6 +35,12 @@ extern "C" {
 
 /* last error text (the reference panics; we return nonzero and keep the panic text) */
 const char *orc_last_error(void);
+/* Return codes of the drivers (orc_makedb / orc_query / orc_cluster / orc_count): 0, or
+ *   ORC_ERR_PANIC   where the reference panics (panic!, .expect(), .unwrap(), slice index) — the binary exits 101;
+ *   ORC_ERR_RESULT  where it returns Err through `?` (File::open / File::create / postcard / everything in count:
+ *                   src/lib.rs:161-162,208-210,214,218,381,385) — main prints "Error: .." and the binary exits 1. */
+#define ORC_ERR_PANIC (-1)
+#define ORC_ERR_RESULT (-2)
 
 /* ---- encoding: src/lib.rs:167-196 (LUT), src/lib.rs:29-52 (12 symbols per u64) ---- */
 uint8_t orc_lut_nt(uint8_t byte); /* 0 = not a nucleotide */

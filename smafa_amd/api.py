@@ -169,6 +169,17 @@ class SubjectStore:
         check(lib().smafa_scan_launch(self._h, qset._h, _opt(max_divergence), _opt(max_num_hits),
                                       C.c_void_p(d_hits), cap, C.c_void_p(d_count)))
 
+    def scan_each(self, qset: QuerySet, max_divergence: Optional[int], d_hits: int, cap_per_query: int, d_counts: int,
+                  use_graph: bool = False) -> None:
+        """one store pass per query, enqueued back to back (smafa_scan_each)"""
+        check(lib().smafa_scan_each(self._h, qset._h, _opt(max_divergence), C.c_void_p(d_hits), cap_per_query,
+                                    C.c_void_p(d_counts), 1 if use_graph else 0))
+
+    def last_call_stats(self) -> dict:
+        ms, n, k = C.c_float(0), C.c_uint32(0), C.c_uint32(0)
+        check(lib().smafa_last_call_stats(self._h, C.byref(ms), C.byref(n), C.byref(k)))
+        return {"kernel_ms": ms.value, "launches": n.value, "scans": k.value}
+
     def sync(self) -> None:
         check(lib().smafa_sync(self._h))
 
@@ -190,6 +201,64 @@ class SubjectStore:
     def close(self):
         if self._h:
             lib().smafa_db_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SubjectGroup:
+    """One WindowSet replicated over several GPUs behind one handle (smafa_group_*): `scan` has the contract of
+    SubjectStore.scan, the batch cut into contiguous blocks, one per device (the loop of src/lib.rs:232-318 sharded)."""
+
+    def __init__(self, seq_len: int, alphabet: int = ALPHABET_NT, devices=(0,)):
+        self._h = C.c_void_p()
+        self.seq_len, self.alphabet = int(seq_len), alphabet
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        check(lib().smafa_group_create(C.byref(self._h), arr, len(devices), alphabet, self.seq_len))
+
+    @classmethod
+    def load(cls, path: str, devices=(0,)) -> "SubjectGroup":
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        check(lib().smafa_group_load(C.byref(self._h), arr, len(devices), os.fsencode(path)))
+        info = _lib.DbInfo()
+        check(lib().smafa_db_info(lib().smafa_group_member(self._h, 0), C.byref(info)))
+        self.seq_len, self.alphabet = int(info.seq_len), int(info.alphabet)
+        return self
+
+    def __len__(self) -> int:
+        return lib().smafa_group_size(self._h)
+
+    def push(self, codes: np.ndarray) -> None:
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        if c.ndim != 2 or c.shape[1] != self.seq_len:
+            raise SmafaPanic(_lib.ERR_PANIC, "WindowSet seq length is %d, got a new sequence of length %d"
+                             % (self.seq_len, c.shape[-1]))
+        check(lib().smafa_group_append(self._h, c.ctypes.data, c.shape[0]))
+
+    def scan(self, query_codes: np.ndarray, max_divergence: Optional[int] = None,
+             max_num_hits: Optional[int] = None, cap: int = 1 << 16) -> np.ndarray:
+        q = np.ascontiguousarray(query_codes, dtype=np.uint8)
+        assert q.ndim == 2 and q.shape[1] == self.seq_len
+        while True:
+            out = np.zeros(max(cap, 1), dtype=HIT_DTYPE)
+            n_out = C.c_uint64(0)
+            rc = lib().smafa_group_scan_hits(self._h, q.ctypes.data, q.shape[0], _opt(max_divergence), _opt(max_num_hits),
+                                             out.ctypes.data, cap, C.byref(n_out))
+            if rc == _lib.ERR_CAPACITY:
+                cap = int(n_out.value)
+                continue
+            check(rc)
+            return out[: n_out.value]
+
+    def close(self):
+        if self._h:
+            lib().smafa_group_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -30,7 +31,7 @@ struct SubjectRows {
     const uint8_t *codes = nullptr;
     const PackedStore *packed = nullptr;
     uint32_t L = 0;
-    void get(uint64_t j, uint8_t *out) const;  // L code bytes of subject j
+    int get(uint64_t j, uint8_t *out) const;  // L code bytes of subject j; fails on a damaged packed store
 };
 // selection rules of src/lib.rs:241-315 (see smafa_select_rows in the public header)
 int select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint64_t n_subjects,
@@ -38,6 +39,13 @@ int select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint
                 std::vector<smafa_hit> &rows);
 // a store handle whose HBM image comes straight from a mapped packed store file
 int db_load_packed(smafa_db **out, int device, const PackedStore &pk);
+
+// ---- a store replicated over several devices behind one handle (host/group.cpp; public: smafa_group_*)
+// fn(g) for every member on its own host thread; first failure in member order
+int group_on_every_handle(smafa_group *grp, const std::function<int(int)> &fn);
+int group_load_packed(smafa_group **out, const int *devices, int ndev, const PackedStore &pk);
+smafa_db *group_member(smafa_group *grp, int g);
+int group_size(const smafa_group *grp);
 
 // stderr logging of the drivers (host/common.cpp): level 1 = info, 2 = debug
 int verbosity();

@@ -75,6 +75,13 @@ struct smafa_db {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     uint32_t last_launches = 0;
+    // totals over the scans of the most recent host-buffer call (smafa_scan_hits: the near-hit ladder and the tightening
+    // path are several scans): smafa_last_call_stats
+    float call_ms = 0.f;
+    uint32_t call_launches = 0, call_scans = 0;
+    // smafa_scan_each: the K one-query launches captured once as a HIP graph and replayed
+    hipGraphExec_t each_graph = nullptr;
+    struct EachKey { const void *qs, *hits, *counts; uint64_t cap, nq, generation; uint32_t max_div; int zone; bool filter; } each_key{};
     uint32_t qb_override = 0;
     bool use_filter = true;  // exact lower-bound prefilter in the scan kernel (SMAFA_FILTER=0 disables)
     uint32_t tiles_override = 0;  // SMAFA_TILES
@@ -94,7 +101,7 @@ struct smafa_db {
     DevBuf idx_a, idx_b;      // sort payload of an append: source row per sorted position
     // ---- layout of the packed store (fixed when the first rows arrive)
     bool layout_set = false;
-    std::vector<uint16_t> perm;  // packed column j holds source column perm[j]
+    std::vector<uint32_t> perm;  // packed column j holds source column perm[j]
     std::vector<uint8_t> tab;    // [source column][code] -> stored code
     DevBuf d_perm, d_tab;
     uint32_t *d_order = nullptr;  // position -> subject index (cap_tiles * 256 entries)
@@ -150,10 +157,10 @@ static int use_device(const smafa_db *db) {
 // Decided once per handle, from a sample of the first rows it receives (compute_layout, host/layout.cpp).
 static int choose_layout(smafa_db *db, const uint8_t *codes, uint64_t n) {
     compute_layout(db->alphabet, db->L, codes, n, db->perm, db->tab);  // host/layout.cpp
-    int rc = db->d_perm.ensure(db->perm.size() * sizeof(uint16_t));
+    int rc = db->d_perm.ensure(db->perm.size() * sizeof(uint32_t));
     if (!rc) rc = db->d_tab.ensure(db->tab.size());
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(db->d_perm.p, db->perm.data(), db->perm.size() * sizeof(uint16_t), hipMemcpyHostToDevice, db->stream));
+    HIP_TRY(hipMemcpyAsync(db->d_perm.p, db->perm.data(), db->perm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, db->stream));
     HIP_TRY(hipMemcpyAsync(db->d_tab.p, db->tab.data(), db->tab.size(), hipMemcpyHostToDevice, db->stream));
     HIP_TRY(hipStreamSynchronize(db->stream));  // the vectors may be reallocated later; the copy is done now
     db->layout_set = true;
@@ -166,7 +173,7 @@ static void launch_pack(smafa_db *db, const uint8_t *d_codes, const uint32_t *d_
     const uint64_t groups = (first + n + 63) / 64 - first / 64;
     const uint32_t blocks = (uint32_t)((groups + kWgWaves - 1) / kWgWaves);
     hipLaunchKernelGGL(pack_rows_kernel<P>, dim3(blocks), dim3(256), 0, db->stream, d_codes, d_src, first, n, db->L, db->W,
-                       d_out, mode, db->QS, db->d_perm.as<uint16_t>(), db->d_tab.as<uint8_t>(), d_order);
+                       d_out, mode, db->QS, db->d_perm.as<uint32_t>(), db->d_tab.as<uint8_t>(), d_order);
 }
 
 // fold the zone words of tiles [t0, t0 + count) into the store's shared-bit statistics (a re-computed tile replaces its
@@ -211,7 +218,7 @@ static int pack_rows(smafa_db *db, const uint8_t *codes, uint64_t first, uint64_
         unsigned long long *ka = db->keys_a.as<unsigned long long>(), *kb = db->keys_b.as<unsigned long long>();
         uint32_t *ia = db->idx_a.as<uint32_t>(), *ib = db->idx_b.as<uint32_t>();
         hipLaunchKernelGGL(row_keys_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, db->stream, d_codes, n, db->L,
-                           db->d_perm.as<uint16_t>(), db->d_tab.as<uint8_t>(), ka, ia);
+                           db->d_perm.as<uint32_t>(), db->d_tab.as<uint8_t>(), ka, ia);
         size_t tmp_bytes = 0;
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ka, kb, ia, ib, (int)n, 0, 64, db->stream));
         rc = db->sort_tmp.ensure(tmp_bytes);
@@ -258,16 +265,21 @@ static int resort_store(smafa_db *db) {
     if (!rc) rc = db->idx_b.ensure(n * sizeof(uint32_t));
     if (rc) return rc;
     uint32_t *d_new = nullptr, *d_order = nullptr;
+    uint4 *d_zone = nullptr;  // the new zone words go to their own buffer: the live ones stay valid until the swap below
     const size_t bytes = db->cap_tiles * db->tile_words() * sizeof(uint32_t);
     const size_t order_bytes = db->cap_tiles * kWaveTile * sizeof(uint32_t);
-    if (hipMalloc(&d_new, bytes) != hipSuccess || hipMalloc(&d_order, order_bytes) != hipSuccess) {
+    const size_t zone_bytes = db->cap_tiles * sizeof(uint4);
+    if (hipMalloc(&d_new, bytes) != hipSuccess || hipMalloc(&d_order, order_bytes) != hipSuccess ||
+        hipMalloc(&d_zone, zone_bytes) != hipSuccess) {
         (void)hipGetLastError();
         if (d_new) (void)hipFree(d_new);
+        if (d_order) (void)hipFree(d_order);
         return SMAFA_OK;
     }
     auto fail = [&](int code) {
         (void)hipFree(d_new);
         (void)hipFree(d_order);
+        (void)hipFree(d_zone);
         return code;
     };
     unsigned long long *ka = db->keys_a.as<unsigned long long>(), *kb = db->keys_b.as<unsigned long long>();
@@ -275,6 +287,7 @@ static int resort_store(smafa_db *db) {
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
     hipError_t e = hipMemsetAsync(d_new, 0, bytes, db->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_order, 0, order_bytes, db->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_zone, 0, zone_bytes, db->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(position_keys_kernel, dim3(blocks), dim3(256), 0, db->stream, db->d_planes, db->P, db->W, n, ka, ia);
         e = hipGetLastError();
@@ -292,16 +305,19 @@ static int resort_store(smafa_db *db) {
     std::vector<uint4> z(n_tiles);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(zone_kernel, dim3((n_tiles + kWgWaves - 1) / kWgWaves), dim3(256), 0, db->stream,
-                           reinterpret_cast<const uint4 *>(d_new), db->P, db->W, db->L, 0u, n_tiles, (uint32_t)n, db->d_zone);
+                           reinterpret_cast<const uint4 *>(d_new), db->P, db->W, db->L, 0u, n_tiles, (uint32_t)n, d_zone);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(z.data(), db->d_zone, z.size() * sizeof(uint4), hipMemcpyDeviceToHost, db->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(z.data(), d_zone, z.size() * sizeof(uint4), hipMemcpyDeviceToHost, db->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
     if (e != hipSuccess) return fail(set_error(SMAFA_ERR_DEVICE, "re-sorting the store failed: %s", hipGetErrorString(e)));
+    // planes, order and zone words change hands together: a failure above leaves the handle exactly as it was
     (void)hipFree(db->d_planes);
     (void)hipFree(db->d_order);
+    (void)hipFree(db->d_zone);
     db->d_planes = d_new;
     db->d_order = d_order;
+    db->d_zone = d_zone;
     db->tile_bits.clear();
     for (uint64_t &h : db->zone_hist) h = 0;
     note_zone_words(db, 0, z.data(), z.size());
@@ -781,6 +797,14 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     return SMAFA_OK;
 }
 
+// the stream has just been synchronised after a scan_range: fold its kernel time into the call's totals
+static void note_call_scan(smafa_db *db) {
+    db->call_scans++;
+    db->call_launches += db->last_launches;
+    float ms = 0.f;
+    if (db->timed && hipEventElapsedTime(&ms, db->ev0, db->ev1) == hipSuccess) db->call_ms += ms;
+}
+
 static bool hit_less(const smafa_hit &x, const smafa_hit &y) {
     if (x.query != y.query) return x.query < y.query;
     if (x.dist != y.dist) return x.dist < y.dist;
@@ -892,6 +916,7 @@ static int collect_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(&count, db->count.p, sizeof count, hipMemcpyDeviceToHost, db->stream));
         HIP_TRY(hipStreamSynchronize(db->stream));
+        note_call_scan(db);
         done = count <= db->hits_cap();
     }
     if (!done) {
@@ -938,6 +963,8 @@ int db_clear(smafa_db *db) {
 int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div,
                  uint32_t max_num_hits, std::vector<smafa_hit> &out) {
     out.clear();
+    db->call_ms = 0.f;
+    db->call_launches = db->call_scans = 0;
     if (n_queries == 0) return SMAFA_OK;
     if (n_queries > 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many queries in one batch");
     int rc = use_device(db);
@@ -999,6 +1026,7 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(&count, db->count.p, sizeof count, hipMemcpyDeviceToHost, db->stream));
         HIP_TRY(hipStreamSynchronize(db->stream));
+        note_call_scan(db);
         if (count == 0 || count > db->hits_cap()) break;  // nobody near / too dense to look at: the full path decides
         std::vector<smafa_hit> near;
         rc = fetch_rows(db, count, 0, cur_n, near);
@@ -1082,10 +1110,10 @@ int db_load_packed(smafa_db **out, int device, const PackedStore &pk) {
     db->P = pk.h.planes;
     db->perm.assign(pk.perm, pk.perm + (size_t)db->W * 32);
     db->tab.assign(pk.tab, pk.tab + (size_t)db->L * 32);
-    rc = db->d_perm.ensure(db->perm.size() * sizeof(uint16_t));
+    rc = db->d_perm.ensure(db->perm.size() * sizeof(uint32_t));
     if (!rc) rc = db->d_tab.ensure(db->tab.size());
     if (rc) return fail(rc);
-    hipError_t e = hipMemcpyAsync(db->d_perm.p, db->perm.data(), db->perm.size() * sizeof(uint16_t), hipMemcpyHostToDevice, db->stream);
+    hipError_t e = hipMemcpyAsync(db->d_perm.p, db->perm.data(), db->perm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, db->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(db->d_tab.p, db->tab.data(), db->tab.size(), hipMemcpyHostToDevice, db->stream);
     db->layout_set = true;
     if (e == hipSuccess && pk.h.n > 0) {
@@ -1201,6 +1229,9 @@ int smafa_db_append(smafa_db *db, const uint8_t *codes, uint64_t n) {
     if (rc) return rc;
     db->n += n;
     db->rows_since_sort += n;
+    // a store that is still ONE sorted run (the bulk load itself) has nothing to gain from a re-sort: the quarter rule
+    // counts growth since the store was last in one sorted run
+    if (db->runs.size() == 1 && db->runs[0].sorted) db->rows_since_sort = 0;
     db->generation++;
     if (n > (1u << 20)) {  // a bulk load's staging and sort buffers are not worth keeping
         for (DevBuf *b : {&db->upload, &db->keys_a, &db->keys_b, &db->idx_a, &db->idx_b, &db->sort_tmp}) b->release();
@@ -1280,6 +1311,7 @@ void smafa_db_destroy(smafa_db *db) {
                       &db->idx_a, &db->idx_b, &db->d_perm, &db->d_tab, &db->scratch_q.qrec,
                       &db->scratch_q.thr, &db->scratch_q.cnt, &db->scratch_q2.qrec, &db->scratch_q2.thr, &db->scratch_q2.cnt})
         b->release();
+    if (db->each_graph) (void)hipGraphExecDestroy(db->each_graph);
     if (db->ev0) (void)hipEventDestroy(db->ev0);
     if (db->ev1) (void)hipEventDestroy(db->ev1);
     if (db->own_stream) (void)hipStreamDestroy(db->own_stream);
@@ -1406,6 +1438,85 @@ int smafa_scan_launch(smafa_db *db, smafa_qset *qs, uint32_t max_div, uint32_t m
     if (!d_hits) d_hits = db->ctrs.p;
     return scan_range(db, qs, 0, (uint32_t)qs->nq, max_div, max_num_hits == SMAFA_NONE ? 0u : max_num_hits,
                       (smafa_hit *)d_hits, cap, (unsigned long long *)d_count);
+}
+
+// One pass over the store PER QUERY (north_star's literal "each query is broadcast against all subjects"), the passes
+// enqueued back to back by this one call: query i's rows go to d_hits + i * cap_per_query, its exact count to d_counts[i].
+// Each pass is the complete one-launch fixed-bound scan of smafa_scan_launch for a one-query set (same kernel choice: a
+// sorted store takes scan_zone_few_kernel unless the zone level is off, then the pass streams the prefilter's plane).
+// use_graph: the passes are captured once as a HIP graph and replayed while the arguments stay the same — no launch
+// gap on the host side at all.
+int smafa_scan_each(smafa_db *db, smafa_qset *qs, uint32_t max_div, void *d_hits, uint64_t cap_per_query, void *d_counts,
+                    int use_graph) {
+    if (!db || !qs || !d_counts || (!d_hits && cap_per_query)) return set_error(SMAFA_ERR_INVALID, "smafa_scan_each: NULL argument");
+    if (qs->db != db) return set_error(SMAFA_ERR_INVALID, "query set was packed for a different store");
+    int rc = use_device(db);
+    if (rc) return rc;
+    db->last_launches = 0;
+    db->timed = false;
+    const uint32_t nq = (uint32_t)qs->nq;
+    if (nq == 0) return SMAFA_OK;
+    if (db->n == 0) {
+        HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nq * sizeof(unsigned long long), db->stream));
+        return SMAFA_OK;
+    }
+    rc = maybe_resort(db);
+    if (rc) return rc;
+    if (!d_hits) d_hits = db->ctrs.p;  // count-only: see smafa_scan_launch
+    const uint32_t thr0 = std::min<uint32_t>(max_div, db->L);
+    const uint32_t n_tiles = (uint32_t)((db->n + kWaveTile - 1) / kWaveTile);
+    auto enqueue = [&]() -> int {
+        for (uint32_t q = 0; q < nq; q++) {
+            int r = launch_tiles(db, qs, q, q + 1, 0, n_tiles, 0, thr0, (smafa_hit *)d_hits + (size_t)q * cap_per_query,
+                                 cap_per_query, (unsigned long long *)d_counts + q);
+            if (r) return r;
+        }
+        return SMAFA_OK;
+    };
+    if (!use_graph) {
+        HIP_TRY(hipEventRecord(db->ev0, db->stream));
+        rc = enqueue();
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(db->ev1, db->stream));
+        db->timed = true;
+        return SMAFA_OK;
+    }
+    const smafa_db::EachKey key{qs, d_hits, d_counts, cap_per_query, qs->nq, db->generation, max_div, db->zone, db->use_filter};
+    if (!db->each_graph || memcmp(&key, &db->each_key, sizeof key) != 0) {
+        if (db->each_graph) (void)hipGraphExecDestroy(db->each_graph);
+        db->each_graph = nullptr;
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(db->stream, hipStreamCaptureModeThreadLocal));
+        rc = enqueue();
+        hipError_t e = hipStreamEndCapture(db->stream, &graph);
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e != hipSuccess) return set_error(SMAFA_ERR_DEVICE, "graph capture failed: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&db->each_graph, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+            db->each_graph = nullptr;
+            return set_error(SMAFA_ERR_DEVICE, "graph instantiation failed: %s", hipGetErrorString(e));
+        }
+        memset(&db->each_key, 0, sizeof db->each_key);
+        db->each_key = key;
+    }
+    db->last_launches = nq;
+    HIP_TRY(hipEventRecord(db->ev0, db->stream));
+    HIP_TRY(hipGraphLaunch(db->each_graph, db->stream));
+    HIP_TRY(hipEventRecord(db->ev1, db->stream));
+    db->timed = true;
+    return SMAFA_OK;
+}
+
+int smafa_last_call_stats(smafa_db *db, float *kernel_ms, uint32_t *n_launches, uint32_t *n_scans) {
+    if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_last_call_stats: NULL handle");
+    if (kernel_ms) *kernel_ms = db->call_ms;
+    if (n_launches) *n_launches = db->call_launches;
+    if (n_scans) *n_scans = db->call_scans;
+    return SMAFA_OK;
 }
 
 int smafa_sync(smafa_db *db) {

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -75,7 +76,10 @@ void append_decoded(std::string &s, int alphabet, const uint8_t *codes, uint32_t
 // lists are formatted by several threads, each into its own buffer over a contiguous slice of the rows.
 int write_rows_text(const smafa_hit *rows, size_t n, const SubjectRows &subjects, int alphabet, uint32_t q_base, int fd) {
     const uint32_t L = subjects.L;
-    auto format = [&](size_t lo, size_t hi, std::string &text) {
+    // (a subject that cannot be read back — a damaged packed store — fails the query; the error text is per thread, so the
+    // first failing slice's code and message are carried to the caller)
+    auto format = [&](size_t lo, size_t hi, std::string &text, int &frc, std::string &fmsg) {
+        frc = SMAFA_OK;
         text.clear();
         text.reserve((hi - lo) * ((size_t)L + 24));
         std::vector<uint8_t> row(L);
@@ -87,30 +91,47 @@ int write_rows_text(const smafa_hit *rows, size_t n, const SubjectRows &subjects
             text.push_back('\t');
             append_u32(text, h.dist);
             text.push_back('\t');
-            subjects.get(h.subject, row.data());
+            frc = subjects.get(h.subject, row.data());
+            if (frc) {
+                fmsg = smafa_last_error();
+                return;
+            }
             append_decoded(text, alphabet, row.data(), L);
             text.push_back('\n');
         }
     };
     const size_t block = 1u << 18;  // rows per write
     const unsigned T = n >= (1u << 16) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-    std::vector<std::string> parts(T);
+    std::vector<std::string> parts(T), msgs(T);
+    std::vector<int> rcs(T, SMAFA_OK);
     for (size_t b0 = 0; b0 < n; b0 += block * T) {
         const size_t b1 = std::min(n, b0 + block * T), span = b1 - b0;
         if (T == 1) {
-            format(b0, b1, parts[0]);
+            format(b0, b1, parts[0], rcs[0], msgs[0]);
         } else {
             std::vector<std::thread> pool;
             for (unsigned t = 0; t < T; t++)
-                pool.emplace_back([&, t] { format(b0 + span * t / T, b0 + span * (t + 1) / T, parts[t]); });
+                pool.emplace_back([&, t] { format(b0 + span * t / T, b0 + span * (t + 1) / T, parts[t], rcs[t], msgs[t]); });
             for (auto &th : pool) th.join();
         }
         for (unsigned t = 0; t < T; t++) {
+            // the rows in front of the damaged one are written, as a sequential writer would have
             int rc = write_all(fd, parts[t].data(), parts[t].size());
             if (rc) return rc;
+            if (rcs[t]) return set_error(rcs[t], "%s", msgs[t].c_str());
         }
     }
     return SMAFA_OK;
+}
+
+// The reference `.expect()`s its FASTX inputs: parse_fastx_file(..).expect(what) on the path and record.expect(what) on
+// every record (src/lib.rs:144,149,221,234; src/cluster.rs:28,39), so an unreadable, empty, non-FASTX or truncated input
+// is a panic — exit 101 — not an Err.  (The DB file is opened with `?`: src/lib.rs:208-210,218 stay SMAFA_ERR_IO /
+// SMAFA_ERR_FORMAT, exit 1; so does everything in `count`, src/lib.rs:381,385.)
+int expect_fastx(int rc, const char *what) {
+    if (rc != SMAFA_ERR_IO && rc != SMAFA_ERR_FORMAT) return rc;
+    const std::string msg = smafa_last_error();
+    return set_error(SMAFA_ERR_PANIC, "%s: %s", what, msg.c_str());
 }
 
 struct DbGuard {
@@ -259,13 +280,13 @@ int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet) {
     BulkRecords recs;
     const double t_start = now_seconds();
     int rc = load_records_bulk(subject_fasta, alphabet, false, recs);  // src/lib.rs:143-152
-    if (rc) return rc;
+    if (rc) return expect_fastx(rc, "valid path/file of subject fasta");  // src/lib.rs:144
     const double t_parsed = now_seconds();
     if (recs.err_kind == 3) return set_error(SMAFA_ERR_PANIC, "Cannot add empty sequence to WindowSet");  // src/lib.rs:103-108
     if (recs.err_kind == 1) return set_error(SMAFA_ERR_PANIC, "%s", recs.err_msg.c_str());                  // src/lib.rs:38-41
     if (recs.err_kind == 2)  // src/lib.rs:92-101
         return set_error(SMAFA_ERR_PANIC, "WindowSet seq length is %zu, got a new sequence of length %zu", recs.L, recs.err_len);
-    if (recs.err_kind == 4) return set_error(SMAFA_ERR_FORMAT, "%s", recs.err_msg.c_str());
+    if (recs.err_kind == 4) return set_error(SMAFA_ERR_PANIC, "valid record: %s", recs.err_msg.c_str());  // src/lib.rs:149
     std::vector<uint8_t> &codes = recs.codes;
     const uint64_t n = recs.n;
     const size_t L = recs.L;
@@ -289,12 +310,12 @@ int smafa_makedb_packed(const char *subject_fasta, const char *db_path, int alph
     int rc = load_records_bulk(subject_fasta, alphabet, false, recs);  // src/lib.rs:143-152
     const double t_parsed = now_seconds();
     warm.join();
-    if (rc) return rc;
+    if (rc) return expect_fastx(rc, "valid path/file of subject fasta");
     if (recs.err_kind == 3) return set_error(SMAFA_ERR_PANIC, "Cannot add empty sequence to WindowSet");
     if (recs.err_kind == 1) return set_error(SMAFA_ERR_PANIC, "%s", recs.err_msg.c_str());
     if (recs.err_kind == 2)
         return set_error(SMAFA_ERR_PANIC, "WindowSet seq length is %zu, got a new sequence of length %zu", recs.L, recs.err_len);
-    if (recs.err_kind == 4) return set_error(SMAFA_ERR_FORMAT, "%s", recs.err_msg.c_str());
+    if (recs.err_kind == 4) return set_error(SMAFA_ERR_PANIC, "valid record: %s", recs.err_msg.c_str());
     if (recs.n == 0) return set_error(SMAFA_ERR_INVALID, "a packed store needs at least one sequence (its length fixes the layout)");
     if (recs.L > 0xffffffffull) return set_error(SMAFA_ERR_INVALID, "sequence too long");
     if (device < 0 || smafa_device_count() == 0) {  // no GPU (or none wanted): the same file, packed by host threads
@@ -385,41 +406,35 @@ int smafa_query_multi(const char *db_path, const char *query_fasta, uint32_t max
     FastxReader reader;
     if (!bulk_queries) {
         rc = reader.open(query_fasta);  // src/lib.rs:221
-        if (rc) return rc;
+        if (rc) return expect_fastx(rc, "valid path/file of query fasta");
     }
 
-    std::vector<DbGuard> guards((size_t)ndev);
-    // run fn(g) for every handle on its own host thread (HIP's current device is per thread); first failure in handle order
-    auto on_every_handle = [&](auto &&fn) -> int {
-        std::vector<int> rcs((size_t)ndev, SMAFA_OK);
-        std::vector<std::string> msgs((size_t)ndev);
-        auto body = [&](int g) {
-            rcs[g] = fn(g);
-            if (rcs[g]) msgs[g] = smafa_last_error();  // the error text is per thread: carry it over
-        };
-        if (ndev == 1) {
-            body(0);
-        } else {
-            std::vector<std::thread> pool;
-            for (int g = 0; g < ndev; g++) pool.emplace_back(body, g);
-            for (auto &th : pool) th.join();
-        }
-        for (int g = 0; g < ndev; g++)
-            if (rcs[g]) return set_error(rcs[g], "%s", msgs[g].c_str());
-        return SMAFA_OK;
-    };
+    // the store on every entry of `devices`: a group (host/group.cpp; public: smafa_group_*)
+    struct GroupGuard {
+        smafa_group *g = nullptr;
+        ~GroupGuard() { smafa_group_destroy(g); }
+    } group;
     if (n > 0) {
         warm.join();
         const double t0 = now_seconds();
-        rc = on_every_handle([&](int g) -> int {
-            if (packed) return db_load_packed(&guards[g].db, devices[g], pk);
-            int r = smafa_db_create(&guards[g].db, devices[g], alphabet, L);
-            if (!r) r = smafa_db_append(guards[g].db, codes, n);
-            return r;
-        });
+        if (packed) {
+            rc = group_load_packed(&group.g, devices, ndev, pk);
+        } else {
+            rc = smafa_group_create(&group.g, devices, ndev, alphabet, L);
+            if (!rc) rc = smafa_group_append(group.g, codes, n);
+        }
         if (rc) return rc;
         log_line(2, "subject store packed into HBM on %d handle(s) in %.2f s", ndev, now_seconds() - t0);
     }
+    // fn(g) for every block of a chunk on its own host thread (without a store: nothing to scan, one thread)
+    auto on_every_handle = [&](const std::function<int(int)> &fn) -> int {
+        if (group.g) return group_on_every_handle(group.g, fn);
+        for (int g = 0; g < ndev; g++) {
+            const int r = fn(g);
+            if (r) return r;
+        }
+        return SMAFA_OK;
+    };
     log_line(1, "Querying ..");  // src/lib.rs:230
     double t_scan = 0;
 
@@ -449,7 +464,7 @@ int smafa_query_multi(const char *db_path, const char *query_fasta, uint32_t max
             block_rows[g].clear();
             if (hi == lo) return SMAFA_OK;
             if (n > 0) {
-                int rr = scan_to_host(guards[g].db, qptr + (size_t)lo * L, hi - lo, max_divergence, dev_k, block_hits[g]);
+                int rr = scan_to_host(group_member(group.g, g), qptr + (size_t)lo * L, hi - lo, max_divergence, dev_k, block_hits[g]);
                 if (rr) return rr;
             }
             return select_rows(block_hits[g].data(), block_hits[g].size(), hi - lo, n, subjects, max_divergence, max_num_hits,
@@ -483,7 +498,7 @@ int smafa_query_multi(const char *db_path, const char *query_fasta, uint32_t max
         // first offending record in file order, like the loop below), then scanned chunk by chunk
         BulkRecords recs;
         rc = load_records_bulk(query_fasta, alphabet, false, recs);
-        if (rc) return rc;
+        if (rc) return expect_fastx(rc, "valid path/file of query fasta");
         uint64_t usable = recs.n;
         if (recs.n > 0 && recs.L != L) {  // the first query already fails the length check: nothing is printed
             usable = 0;
@@ -495,9 +510,9 @@ int smafa_query_multi(const char *db_path, const char *query_fasta, uint32_t max
             length_panic(recs.err_len);
         } else if (recs.err_kind == 3) {
             length_panic(0);
-        } else if (recs.err_kind == 4) {
-            pending = SMAFA_ERR_FORMAT;
-            pending_msg = recs.err_msg;
+        } else if (recs.err_kind == 4) {  // record.expect(..), src/lib.rs:234
+            pending = SMAFA_ERR_PANIC;
+            pending_msg = "Failed to parse query sequence: " + recs.err_msg;
         }
         if (usable > 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many queries");
         for (uint64_t off = 0; off < usable; off += chunk_queries) {
@@ -530,8 +545,8 @@ int smafa_query_multi(const char *db_path, const char *query_fasta, uint32_t max
             }
         }
     }
-    if (rc < 0 && pending == SMAFA_OK) {
-        pending = rc;
+    if (rc < 0 && pending == SMAFA_OK) {  // record.expect("Failed to parse query sequence"), src/lib.rs:234
+        pending = expect_fastx(rc, "Failed to parse query sequence");
         pending_msg = smafa_last_error();
     }
     int frc = flush();
@@ -582,7 +597,7 @@ static int cluster_run(const char *input_fasta, uint32_t max_divergence, int out
     BulkRecords recs;
     rc = load_records_bulk(input_fasta, alphabet, true, recs);  // src/cluster.rs:28,35-43 for every record
     warm.join();
-    if (rc) return rc;
+    if (rc) return expect_fastx(rc, "valid path/file of input fasta");  // src/cluster.rs:28
     std::vector<uint8_t> &raw = recs.raw, &codes = recs.codes;
     const uint64_t n = recs.n;
     const size_t L = recs.L;
@@ -602,9 +617,9 @@ static int cluster_run(const char *input_fasta, uint32_t max_divergence, int out
                  recs.err_len, L);
         pending = SMAFA_ERR_PANIC;
         pending_msg = msg;
-    } else if (recs.err_kind == 4) {
-        pending = SMAFA_ERR_FORMAT;
-        pending_msg = recs.err_msg;
+    } else if (recs.err_kind == 4) {  // record.expect(..), src/cluster.rs:39
+        pending = SMAFA_ERR_PANIC;
+        pending_msg = "Failed to parse input sequence: " + recs.err_msg;
     }
 
     const double t_loaded = now_seconds();

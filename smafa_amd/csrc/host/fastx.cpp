@@ -29,9 +29,9 @@ int FastxReader::open(const char *path) {
     const size_t got = fread(magic, 1, sizeof magic, f);
     fclose(f);
     if (got >= 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h')
-        return set_error(SMAFA_ERR_FORMAT, "%s: bzip2 input is not supported by this build", path);
+        return set_error(SMAFA_ERR_INVALID, "%s: bzip2 input is not supported by this build", path);  // (not a reference panic: exit 1)
     if (got >= 6 && magic[0] == 0xfd && magic[1] == '7' && magic[2] == 'z' && magic[3] == 'X' && magic[4] == 'Z')
-        return set_error(SMAFA_ERR_FORMAT, "%s: xz input is not supported by this build", path);
+        return set_error(SMAFA_ERR_INVALID, "%s: xz input is not supported by this build", path);
     data_.clear();
     if (map_) munmap(map_, size_);
     map_ = nullptr;

@@ -17,7 +17,7 @@
 
 namespace smafa {
 
-void compute_layout(int alphabet, uint32_t L, const uint8_t *codes, uint64_t n, std::vector<uint16_t> &perm,
+void compute_layout(int alphabet, uint32_t L, const uint8_t *codes, uint64_t n, std::vector<uint32_t> &perm,
                     std::vector<uint8_t> &tab) {
     const uint32_t W = (L + 31) / 32;
     const bool aa = alphabet == SMAFA_ALPHABET_AA;
@@ -89,7 +89,7 @@ void compute_layout(int alphabet, uint32_t L, const uint8_t *codes, uint64_t n, 
     for (uint32_t c = 0; c < L; c++) cols[c] = c;
     std::stable_sort(cols.begin(), cols.end(), [&](uint32_t x, uint32_t y) { return score[x] > score[y]; });
     perm.assign((size_t)W * 32, 0);
-    for (uint32_t j = 0; j < L; j++) perm[j] = (uint16_t)cols[j];
+    for (uint32_t j = 0; j < L; j++) perm[j] = cols[j];
 }
 
 static inline uint32_t brev32(uint32_t x) {
@@ -132,7 +132,7 @@ int pack_store_on_host(int alphabet, uint32_t L, const uint8_t *codes, uint64_t 
     const uint8_t max_code = *std::max_element(worst.begin(), worst.end());
     if (max_code >= lim) return set_error(SMAFA_ERR_INVALID, "code byte %u outside the alphabet (max %u)", max_code, lim - 1);
     const uint32_t P = alphabet == SMAFA_ALPHABET_AA ? 5u : (max_code >= 4 ? 3u : 2u);  // nucleotides: 2 planes while there is no N
-    std::vector<uint16_t> perm;
+    std::vector<uint32_t> perm;
     std::vector<uint8_t> tab;
     compute_layout(alphabet, L, codes, n, perm, tab);
     // ---- sort key per row (row_keys_kernel), stable sort (the device's radix sort is stable)

@@ -7,7 +7,7 @@
 //   byte 1      varint(2)        kind: 2 = packed tiles (kind 1 is the raw amino-acid code container of dbfile.cpp)
 //   bytes 2..7  "SMAFA\0"
 //   byte 8      PackedHeader     little-endian, fixed width; every section starts on a 4096-byte boundary
-//   sections    perm  u16[W*32]  packed column j holds source column perm[j]          (layout, engine.hip choose_layout)
+//   sections    perm  u32[W*32]  packed column j holds source column perm[j]          (layout, engine.hip choose_layout)
 //               tab   u8[L*32]   [source column][code] -> stored code
 //               runs  {u64 rows, u64 sorted}[n_runs]   the appends the store was built from (zone-level eligibility)
 //               inv   u32[n]     subject index -> position (for decoding a subject on the host)
@@ -25,6 +25,7 @@
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 namespace smafa {
 
@@ -58,11 +59,11 @@ int PackedStore::open(const char *path) {
     bool ok = (h.alphabet == SMAFA_ALPHABET_NT || aa) && L >= 1 && W == (L + 31) / 32 && (aa ? P == 5 : (P == 2 || P == 3)) &&
               h.n <= 0xffffff00ull && h.n_tiles == (h.n + 255) / 256 && h.file_bytes == map_len_ && h.n_runs <= (1u << 20);
     auto inside = [&](uint64_t off, uint64_t bytes) { return off % 64 == 0 && off <= map_len_ && bytes <= map_len_ - off; };
-    ok = ok && inside(h.off_perm, W * 32 * 2) && inside(h.off_tab, L * 32) && inside(h.off_runs, h.n_runs * 16) &&
+    ok = ok && inside(h.off_perm, W * 32 * 4) && inside(h.off_tab, L * 32) && inside(h.off_runs, h.n_runs * 16) &&
          inside(h.off_inv, h.n * 4) && inside(h.off_order, h.n_tiles * 256 * 4) && inside(h.off_zone, h.n_tiles * 16) &&
          inside(h.off_planes, h.n_tiles * P * W * 256 * 4);
     if (!ok) return set_error(SMAFA_ERR_FORMAT, "%s: malformed packed store header", path);
-    perm = (const uint16_t *)(p + h.off_perm);
+    perm = (const uint32_t *)(p + h.off_perm);
     tab = p + h.off_tab;
     runs = (const uint64_t *)(p + h.off_runs);
     inv = (const uint32_t *)(p + h.off_inv);
@@ -86,6 +87,14 @@ int PackedStore::open(const char *path) {
     uint64_t run_rows = 0;
     for (uint64_t r = 0; r < h.n_runs; r++) run_rows += runs[2 * r];
     if (run_rows != h.n) return set_error(SMAFA_ERR_FORMAT, "%s: run list does not add up to the row count", path);
+    // order: a permutation of the subjects (the device writes out[order[pos]], a scan reports order[pos]); inv: its inverse.
+    // inv[order[pos]] == pos for every pos < n makes order injective into [0, n), hence a permutation, and inv its inverse.
+    for (uint64_t pos = 0; pos < h.n; pos++) {
+        const uint32_t s = order[pos];
+        if (s >= h.n || inv[s] != pos)
+            return set_error(SMAFA_ERR_FORMAT, "%s: subject order table is not a permutation (position %llu)", path,
+                             (unsigned long long)pos);
+    }
     return SMAFA_OK;
 }
 
@@ -108,13 +117,13 @@ int PackedStore::row(uint64_t subject, uint8_t *out) const {
     return SMAFA_OK;
 }
 
-int write_packed_file(const char *path, const PackedHeader &hdr_in, const uint16_t *perm, const uint8_t *tab,
+int write_packed_file(const char *path, const PackedHeader &hdr_in, const uint32_t *perm, const uint8_t *tab,
                       const uint64_t *runs, const uint32_t *order, const void *zone, const uint32_t *planes) {
     PackedHeader h = hdr_in;
     auto align = [](uint64_t x) { return (x + 4095) / 4096 * 4096; };
     const uint64_t L = h.seq_len, W = h.words, P = h.planes;
     uint64_t off = align(sizeof kMagic + sizeof(PackedHeader));
-    h.off_perm = off, off = align(off + W * 32 * 2);
+    h.off_perm = off, off = align(off + W * 32 * 4);
     h.off_tab = off, off = align(off + L * 32);
     h.off_runs = off, off = align(off + h.n_runs * 16);
     h.off_inv = off, off = align(off + h.n * 4);
@@ -127,7 +136,10 @@ int write_packed_file(const char *path, const PackedHeader &hdr_in, const uint16
         if (order[pos] >= h.n) return set_error(SMAFA_ERR_INVALID, "order table entry out of range");
         inv[order[pos]] = (uint32_t)pos;
     }
-    FILE *f = fopen(path, "wb");
+    // written beside the target and renamed over it once complete and on disk: an interrupted `makedb --packed` never
+    // leaves a file with a valid header over a truncated body
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return set_error(SMAFA_ERR_IO, "%s: %s", path, strerror(errno));
     bool ok = true;
     auto put = [&](uint64_t at, const void *p, uint64_t bytes) {
@@ -135,7 +147,7 @@ int write_packed_file(const char *path, const PackedHeader &hdr_in, const uint16
     };
     put(0, kMagic, sizeof kMagic);
     put(sizeof kMagic, &h, sizeof h);
-    put(h.off_perm, perm, W * 32 * 2);
+    put(h.off_perm, perm, W * 32 * 4);
     put(h.off_tab, tab, L * 32);
     put(h.off_runs, runs, h.n_runs * 16);
     put(h.off_inv, inv.data(), h.n * 4);
@@ -143,13 +155,21 @@ int write_packed_file(const char *path, const PackedHeader &hdr_in, const uint16
     put(h.off_zone, zone, h.n_tiles * 16);
     put(h.off_planes, planes, h.n_tiles * P * W * 256 * 4);
     if (ftruncate(fileno(f), (off_t)h.file_bytes) != 0) ok = false;
-    if (fclose(f) != 0 || !ok) return set_error(SMAFA_ERR_IO, "%s: write error", path);
+    if (ok && (fflush(f) != 0 || fsync(fileno(f)) != 0)) ok = false;
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path) != 0) {
+        const int err = errno;
+        (void)unlink(tmp.c_str());
+        return set_error(SMAFA_ERR_IO, "%s: write error: %s", path, strerror(err));
+    }
     return SMAFA_OK;
 }
 
-void SubjectRows::get(uint64_t j, uint8_t *out) const {
-    if (codes) memcpy(out, codes + (size_t)j * L, L);
-    else if (packed->row(j, out) != SMAFA_OK) memset(out, 255, L);  // prints as '?' columns; open() validated the tables
+int SubjectRows::get(uint64_t j, uint8_t *out) const {
+    if (codes) {
+        memcpy(out, codes + (size_t)j * L, L);
+        return SMAFA_OK;
+    }
+    return packed->row(j, out);  // a damaged plane block fails the query instead of printing placeholder columns
 }
 
 }  // namespace smafa

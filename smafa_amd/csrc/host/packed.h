@@ -21,7 +21,7 @@ bool is_packed_file(const uint8_t *p, size_t len);
 class PackedStore {
   public:
     PackedHeader h{};
-    const uint16_t *perm = nullptr;
+    const uint32_t *perm = nullptr;
     const uint8_t *tab = nullptr;
     const uint64_t *runs = nullptr;  // n_runs x {rows, sorted}
     const uint32_t *inv = nullptr, *order = nullptr, *planes = nullptr;
@@ -40,12 +40,12 @@ class PackedStore {
 };
 
 // column order + per-column code table of a store, from a sample of its rows (host/layout.cpp)
-void compute_layout(int alphabet, uint32_t L, const uint8_t *codes, uint64_t n, std::vector<uint16_t> &perm,
+void compute_layout(int alphabet, uint32_t L, const uint8_t *codes, uint64_t n, std::vector<uint32_t> &perm,
                     std::vector<uint8_t> &tab);
 // the packed store file of n code rows, packed on the host (no GPU): the same bytes smafa_db_save writes for them
 int pack_store_on_host(int alphabet, uint32_t L, const uint8_t *codes, uint64_t n, const char *path);
 
-int write_packed_file(const char *path, const PackedHeader &hdr, const uint16_t *perm, const uint8_t *tab,
+int write_packed_file(const char *path, const PackedHeader &hdr, const uint32_t *perm, const uint8_t *tab,
                       const uint64_t *runs, const uint32_t *order, const void *zone, const uint32_t *planes);
 
 }  // namespace smafa

@@ -52,7 +52,8 @@ int select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint
                 const smafa_hit &h = hits[t];
                 if (h.dist > kth || h.dist > max_div) break;  // ordered by distance: nothing further qualifies
                 if (limit_per_sequence != SMAFA_NONE) {       // :269-289, adjacent equal strings only
-                    subjects.get(h.subject, this_row.data());
+                    const int grc = subjects.get(h.subject, this_row.data());
+                    if (grc) return grc;
                     const bool same = have_last && memcmp(last_row.data(), this_row.data(), seq_len) == 0;
                     if (same) {
                         if (last_count >= limit_per_sequence) continue;

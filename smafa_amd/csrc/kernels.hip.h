@@ -948,7 +948,10 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
         dma(0, q0);
         if (!FIXED && tid < (uint32_t)kChunk) nu_lds[0][tid] = load_bound(q0);
     }
-    __syncthreads();  // (drains the DMA: its fence waits for vmcnt(0))
+    // The DMA'd chunk is published by the barrier: every wave waits for its own global_load_lds first (the barrier's
+    // fence does not have to: gfx950's s_barrier has no implicit vmcnt wait).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     bool filter_on = a.use_filter != 0;
     uint32_t chunk_no = 0;
     for (uint32_t qc = q0; qc < q1; qc += kChunk, buf ^= 1, chunk_no++) {
@@ -1082,7 +1085,8 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
             }
         }
         if (more && !FIXED && tid < (uint32_t)kChunk) nu_lds[buf ^ 1][tid] = nu_next;
-        __syncthreads();  // also where the next chunk's DMA is waited for (vmcnt(0) in the barrier's fence)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next chunk's DMA has landed
+        __syncthreads();
         if (a.hits) flush_rows(a, rs, buf);
     }
     finish_rows(a);
@@ -1769,7 +1773,7 @@ __global__ __launch_bounds__(256) void distances_kernel(const uint4 *__restrict_
 template <int P>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *codes, const uint32_t *src, uint64_t first,
                                                         uint64_t n, uint32_t L, uint32_t W, uint32_t *out, int mode,
-                                                        uint32_t QS, const uint16_t *__restrict__ perm,
+                                                        uint32_t QS, const uint32_t *__restrict__ perm,
                                                         const uint8_t *__restrict__ tab, uint32_t *order) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t group = (uint64_t)blockIdx.x * kWgWaves + (threadIdx.x >> 6);
@@ -1838,7 +1842,7 @@ __device__ __forceinline__ uint32_t gray_rank(uint32_t x) {
     return x;
 }
 
-__global__ void row_keys_kernel(const uint8_t *__restrict__ codes, uint64_t n, uint32_t L, const uint16_t *__restrict__ perm,
+__global__ void row_keys_kernel(const uint8_t *__restrict__ codes, uint64_t n, uint32_t L, const uint32_t *__restrict__ perm,
                                 const uint8_t *__restrict__ tab, unsigned long long *__restrict__ keys,
                                 uint32_t *__restrict__ iota) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -250,7 +250,8 @@ def test_cluster_sharded_argument_checks(tmp_path):
     open(empty, "w").close()
     calls = []
     cb = _lib.ALLGATHER_FN(lambda *a: calls.append(a) or 1)
-    assert l.smafa_cluster_sharded(os.fsencode(empty), 3, 1, 0, 0, 1, 2, cb, None) == -5 and not calls
+    assert l.smafa_cluster_sharded(os.fsencode(empty), 3, 1, 0, 0, 1, 2, cb, None) == -6 and not calls  # .expect(..), src/cluster.rs:28
+    assert b"valid path/file of input fasta" in l.smafa_last_error()
 
 
 def test_dbfile_property_any_shape(tmp_path):
@@ -354,6 +355,23 @@ def test_parallel_fastq_and_gzip_ingest_match_oracle(tmp_path):
             assert r.stderr.strip().splitlines()[-1] == o.stderr.strip().splitlines()[-1], path
 
 
+def test_packed_store_of_very_long_sequences(tmp_path):
+    """more than 65 535 columns: the column-order table holds 32-bit entries (a 16-bit table wrapped around and packed
+    duplicated columns); the host packer's file decodes back to the rows"""
+    from smafa_amd import synth
+
+    L, n = 70000, 6
+    rng = np.random.default_rng(11)
+    s = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    s[:, 65536:] = np.where(rng.random((n, L - 65536)) < 0.5, 0, s[:, 65536:])  # columns past 2^16 differ in information
+    fa, pk = str(tmp_path / "long.fa"), str(tmp_path / "long.packed")
+    synth.write_fasta(fa, s, 0)
+    r = cli("makedb", "-i", fa, "-d", pk, "--packed", "--no-gpu")
+    assert r.returncode == 0, r.stderr
+    a, codes = smafa_amd.read_db(pk)
+    assert a == 0 and codes.shape == (n, L) and codes.tobytes() == s.tobytes()
+
+
 def test_db_with_a_non_one_hot_group_is_rejected_at_load(golden, tmp_path):
     """deliberate restriction: the v2 loader refuses windows the reference's makedb cannot produce,
     with its own text (not the reference's print-time panic) — pinned on a mutated copy of the reference's fixture"""
@@ -414,7 +432,12 @@ def test_packed_store_file_written_without_a_gpu(tmp_path, alphabet, n_letters, 
         "perm": lambda b: b.__setitem__(slice(4096, 4098), struct.pack("<H", 60)),
         "tab": lambda b: b.__setitem__(slice(8192, 8194), b"\x00\x00"),
         "offset": lambda b: b.__setitem__(slice(8 + 40 + 48, 8 + 40 + 56), struct.pack("<Q", len(good))),
+        # the subject order (position -> subject: what the device indexes its output with) and its inverse
+        "order_dup": lambda b: b.__setitem__(slice(off_order, off_order + 4), b[off_order + 4:off_order + 8]),
+        "order_big": lambda b: b.__setitem__(slice(off_order + 8, off_order + 12), struct.pack("<I", n + 5)),
+        "inv": lambda b: b.__setitem__(slice(off_inv, off_inv + 4), struct.pack("<I", (struct.unpack_from("<I", b, off_inv)[0] + 1) % n)),
     }
+    off_inv, off_order = struct.unpack_from("<QQ", good, 8 + 40 + 24)
     for name, edit in cases.items():
         with pytest.raises(smafa_amd.SmafaError):
             smafa_amd.read_db(damaged(edit, name))

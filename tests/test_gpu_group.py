@@ -1,0 +1,125 @@
+"""GPU tests of the round-3 entry points: the multi-device group (smafa_group_*), the one-pass-per-query launcher
+(smafa_scan_each) and the per-call totals (smafa_last_call_stats) — all through the C ABI, against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+import smafa_amd
+from smafa_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(a):
+    return np.stack([a["query"], a["subject"], a["dist"]], axis=1).astype(np.uint32)
+
+
+def _select_k(want, k):
+    """oracle rows (every pair within the bound, ordered) -> the rows within each query's k-th smallest distance"""
+    out = []
+    for q in np.unique(want["query"]):
+        r = want[want["query"] == q]
+        kth = r["dist"][k - 1] if len(r) >= k else np.iinfo(np.uint32).max
+        out.append(r[r["dist"] <= kth])
+    return np.concatenate(out) if out else want[:0]
+
+
+@pytest.mark.parametrize("alphabet", [smafa_amd.ALPHABET_NT, smafa_amd.ALPHABET_AA])
+def test_group_rows_do_not_depend_on_the_number_of_handles(alphabet):
+    """src/lib.rs:232-318 sharded: N in {1, 2, 3} handles (all on GPU 0) return byte-identical rows == the oracle's, for a
+    fixed bound, best hit (k = 1) and k = 5; the store arrives in two appends"""
+    n, L, nq = 40_000, 60, 1_001
+    subj = synth.subjects(n, L, alphabet, seed=21)
+    qry, _, _ = synth.queries(subj, nq, alphabet, seed=22, max_subs=8)
+    D = 5
+    want = oracle.scan_codes(subj, qry, D)
+    everything = oracle.scan_codes(subj, qry[:64], L)  # every pair: the k-th modes without a bound, on 64 queries
+    got = {}
+    for ndev in (1, 2, 3):
+        g = smafa_amd.SubjectGroup(L, alphabet, devices=[0] * ndev)
+        assert len(g) == ndev
+        g.push(subj[:25_000])
+        g.push(subj[25_000:])
+        fixed = g.scan(qry, max_divergence=D)
+        assert _rows(fixed).tobytes() == _rows(want).tobytes()
+        best = g.scan(qry[:64], max_num_hits=1)
+        assert _rows(best).tobytes() == _rows(_select_k(everything, 1)).tobytes()
+        k5 = g.scan(qry[:64], max_divergence=40, max_num_hits=5)
+        w5 = _select_k(everything[everything["dist"] <= 40], 5)
+        assert _rows(k5).tobytes() == _rows(w5).tobytes()
+        # grow-and-retry: a buffer that is too small reports the size and the repeated call is answered
+        small = g.scan(qry, max_divergence=D, cap=3)
+        assert _rows(small).tobytes() == _rows(want).tobytes()
+        got[ndev] = (fixed.tobytes(), best.tobytes(), k5.tobytes())
+        g.close()
+    assert got[1] == got[2] == got[3]
+
+
+def test_group_from_a_packed_store_file(tmp_path):
+    n, L = 20_000, 60
+    subj = synth.subjects(n, L, 0, seed=5)
+    qry, _, _ = synth.queries(subj, 300, 0, seed=6, max_subs=6)
+    one = smafa_amd.SubjectStore(L, 0, 0)
+    one.push(subj)
+    path = str(tmp_path / "s.packed")
+    one.save(path)
+    want = one.scan(qry, max_divergence=3)
+    one.close()
+    g = smafa_amd.SubjectGroup.load(path, devices=[0, 0])
+    assert _rows(g.scan(qry, max_divergence=3)).tobytes() == _rows(want).tobytes()
+    assert _rows(want).tobytes() == _rows(oracle.scan_codes(subj, qry, 3)).tobytes()
+    g.close()
+
+
+@pytest.mark.parametrize("zone_level", [0, 1, 2])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_scan_each_equals_the_batch_scan(zone_level, use_graph):
+    """one store pass per query, enqueued back to back: query i's rows and exact count == its rows in the batch scan"""
+    import torch
+
+    n, L, nq, D, cap = 300_000, 60, 24, 5, 64
+    subj = synth.subjects(n, L, 1, seed=31)
+    subj[1000:1040] = subj[999]  # a dense spot: one query with 41 rows
+    qry, _, _ = synth.queries(subj, nq, 1, seed=32, max_subs=7)
+    qry[3] = subj[999]
+    store = smafa_amd.SubjectStore(L, 1, 0)
+    store.push(subj)
+    store.set_zone_level(zone_level)
+    want = oracle.scan_codes(subj, qry, D)
+    qs = smafa_amd.QuerySet(store, qry)
+    dev = torch.device("cuda", 0)
+    hits = torch.zeros(nq * cap * 3, dtype=torch.int32, device=dev)
+    counts = torch.full((nq,), -1, dtype=torch.int64, device=dev)
+    for rep in range(3):  # the graph is captured by the first call and replayed by the others
+        counts.fill_(-1)
+        store.scan_each(qs, D, hits.data_ptr(), cap, counts.data_ptr(), use_graph=use_graph)
+        store.sync()
+        c = counts.cpu().numpy()
+        h = hits.cpu().numpy().view(np.uint32).reshape(nq, cap, 3)
+        for q in range(nq):
+            w = want[want["query"] == q]
+            assert c[q] == len(w), (q, c[q], len(w))
+            r = h[q, : c[q]]  # rows carry the query's index in the set; within a pass they arrive in any order
+            r = r[np.lexsort((r[:, 1], r[:, 2], r[:, 0]))]
+            assert r.tobytes() == _rows(w).tobytes(), (q, rep)
+    qs.close()
+    store.close()
+
+
+def test_last_call_stats_cover_every_scan_of_a_call():
+    n, L = 200_000, 60
+    subj = synth.subjects(n, L, 1, seed=41)
+    near, _, _ = synth.queries(subj, 64, 1, seed=42, max_subs=4)
+    far = synth.subjects(64, L, 1, seed=43, dup_frac=0.0)  # unrelated to every subject
+    store = smafa_amd.SubjectStore(L, 1, 0)
+    store.push(subj)
+    rows = store.scan(np.concatenate([near, far]), max_num_hits=1)  # best hit, no bound: ladder + tightening path
+    st = store.last_call_stats()
+    assert st["scans"] >= 2 and st["launches"] >= st["scans"] and st["kernel_ms"] > 0
+    assert len(np.unique(rows["query"])) == 128  # every query has a best hit
+    store.scan(near, max_divergence=5)
+    st1 = store.last_call_stats()
+    assert st1["scans"] == 1 and st1["launches"] == 1
+    store.close()
