@@ -238,6 +238,14 @@ int smafa_fastx_load(const char *path, int alphabet, uint8_t **codes, uint64_t *
  * smafa_fastx_load would have failed with (message in smafa_last_error()) or SMAFA_OK.  For hosts that — like the
  * reference's loop, src/lib.rs:232-318 — answer the queries in front of a bad record before they fail. */
 int smafa_fastx_load_partial(const char *path, int alphabet, uint8_t **codes, uint64_t *n, uint32_t *seq_len, int *pending);
+/* One PART of a plain FASTA/FASTQ file, for hosts that shard a query file over processes: the records that start in this
+ * part's byte range (part p of `parts`: the first record start at or after byte size*p/parts up to the next part's) — the
+ * parts partition the records in file order and a process reads only its own bytes.  *usable = 0 (and no rows): the file
+ * cannot be taken in parts (gzip, a cut that did not hold, a malformed record) — load the whole file instead.  *seq_len =
+ * the length of the part's first record; *pending as in smafa_fastx_load_partial.  (parse_fastx_file + the loop of
+ * src/lib.rs:221,232-235, one share of it.) */
+int smafa_fastx_load_part(const char *path, int alphabet, uint32_t part, uint32_t parts, uint8_t **codes, uint64_t *n,
+                          uint32_t *seq_len, int *pending, int *usable);
 void smafa_free(void *p);
 
 /* ------------------------------------------- drivers: the crate's pub fns */
@@ -258,6 +266,27 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
  * but the running query number, so the bytes written do not depend on ndev.  No collective, no torch. */
 int smafa_query_multi(const char *db_path, const char *query_fasta, uint32_t max_divergence, uint32_t max_num_hits,
                       uint32_t limit_per_sequence, int out_fd, const int *devices, int ndev);
+/* ---- `query` for hosts that run ONE PROCESS PER GPU (smafa_amd/dist.py over torch.distributed / RCCL, or MPI) ----
+ * The loop of src/lib.rs:232-318 carries no state between records but the running query number, so the query FILE is cut
+ * into `parts` contiguous shares in rank order.  A process opens the DB once (a packed store file is mapped and copied to
+ * HBM: no decode, no host code rows), answers its share — reading ONLY its byte range of a plain FASTA/FASTQ file — and
+ * rank 0 prints the gathered rows, decoding subject strings for the hit rows only.
+ *   smafa_qsession_scan_part: rows (malloc'd, free with smafa_free) are numbered from 0 within the share and already
+ *   selected (src/lib.rs:241-315); *n_queries = records of the share that were answered; *pending = SMAFA_OK or the code of
+ *   the first record the reference's loop fails on inside this share (text in smafa_last_error()): the caller prints the
+ *   rows of the ranks up to and including the first such rank, then fails with that text.
+ *   whole_file = 0: the share is the records that start in this part's byte range; *n_before = UINT64_MAX (the caller
+ *   adds up the counts of the ranks in front); *retry_whole = 1 (and nothing else) when the file cannot be taken in parts
+ *   (gzip, a cut that did not hold, a malformed record): EVERY rank must then call again with whole_file = 1 — the whole
+ *   file is parsed, the share is block [part*Q/parts, (part+1)*Q/parts) of its Q usable records and *n_before its start. */
+typedef struct smafa_qsession smafa_qsession;
+int smafa_qsession_open(smafa_qsession **out, const char *db_path, int device); /* device < 0: no store in HBM (printing only) */
+int smafa_qsession_info(const smafa_qsession *s, uint64_t *n_subjects, uint32_t *seq_len, int *alphabet);
+int smafa_qsession_scan_part(smafa_qsession *s, const char *query_fasta, uint32_t max_divergence, uint32_t max_num_hits,
+                             uint32_t limit_per_sequence, uint32_t part, uint32_t parts, int whole_file, smafa_hit **rows,
+                             uint64_t *n_rows, uint64_t *n_queries, uint64_t *n_before, int *pending, int *retry_whole);
+int smafa_qsession_write(smafa_qsession *s, const smafa_hit *rows, uint64_t n_rows, int out_fd);
+void smafa_qsession_close(smafa_qsession *s); /* NULL-safe */
 /* cluster(input_fasta, max_divergence, print_stream) — src/cluster.rs:13-94. */
 int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet);
 /* The same clustering spread over `world` processes, one GPU each (cluster mode): every rank reads

@@ -5,4 +5,4 @@ mirror of the reference crate's interface for that path.  No CPU fallback.
 """
 from ._lib import ALPHABET_AA, ALPHABET_NT, NONE, SmafaError, SmafaPanic, build  # noqa: F401
 from .api import (HIT_DTYPE, QuerySet, SubjectGroup, SubjectStore, build_id, cluster, hbm_read_probe, count, decode, device_count, encode,  # noqa: F401
-                  encode_rows, load_fastx, makedb, makedb_packed, query, read_db, select_rows, write_db, write_rows)
+                  encode_rows, load_fastx, load_fastx_part, makedb, makedb_packed, query, read_db, select_rows, write_db, write_rows)

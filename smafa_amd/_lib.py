@@ -28,9 +28,10 @@ EXPORTS = [
     "smafa_scan_hits", "smafa_distances", "smafa_qset_create", "smafa_qset_destroy", "smafa_scan_launch",
     "smafa_scan_each", "smafa_last_call_stats",
     "smafa_sync", "smafa_last_scan_ms", "smafa_last_scan_plan", "smafa_last_scan_kernel", "smafa_build_id", "smafa_hbm_read_probe", "smafa_set_query_block", "smafa_set_prefilter", "smafa_set_zone_level", "smafa_select_rows", "smafa_write_rows",
-    "smafa_dbfile_write", "smafa_dbfile_read", "smafa_fastx_load", "smafa_fastx_load_partial", "smafa_free",
+    "smafa_dbfile_write", "smafa_dbfile_read", "smafa_fastx_load", "smafa_fastx_load_partial", "smafa_fastx_load_part", "smafa_free",
     "smafa_group_create", "smafa_group_load", "smafa_group_append", "smafa_group_scan_hits", "smafa_group_size",
     "smafa_group_member", "smafa_group_destroy",
+    "smafa_qsession_open", "smafa_qsession_info", "smafa_qsession_scan_part", "smafa_qsession_write", "smafa_qsession_close",
     "smafa_makedb", "smafa_makedb_packed", "smafa_query", "smafa_query_multi", "smafa_cluster", "smafa_cluster_sharded", "smafa_count",
 ]
 
@@ -116,6 +117,13 @@ def lib() -> C.CDLL:
     l.smafa_group_member.restype = vp
     l.smafa_group_destroy.argtypes = [vp]
     l.smafa_group_destroy.restype = None
+    l.smafa_qsession_open.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int]
+    l.smafa_qsession_info.argtypes = [vp, u64p, u32p, C.POINTER(C.c_int)]
+    l.smafa_qsession_scan_part.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                           C.POINTER(vp), u64p, u64p, u64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    l.smafa_qsession_write.argtypes = [vp, vp, C.c_uint64, C.c_int]
+    l.smafa_qsession_close.argtypes = [vp]
+    l.smafa_qsession_close.restype = None
     l.smafa_select_rows.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_uint32, vp, C.c_uint64, u64p]
     l.smafa_write_rows.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_int]
@@ -123,6 +131,8 @@ def lib() -> C.CDLL:
     l.smafa_dbfile_read.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(vp), u64p, u32p]
     l.smafa_fastx_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), u64p, u32p]
     l.smafa_fastx_load_partial.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), u64p, u32p, C.POINTER(C.c_int)]
+    l.smafa_fastx_load_part.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(vp), u64p, u32p, C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int)]
     l.smafa_free.argtypes = [vp]
     l.smafa_free.restype = None
     l.smafa_makedb.argtypes = [C.c_char_p, C.c_char_p, C.c_int]

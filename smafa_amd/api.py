@@ -326,6 +326,23 @@ def load_fastx_partial(path: str, alphabet: int = ALPHABET_NT):
     return arr.reshape(n.value, L.value), err
 
 
+def load_fastx_part(path: str, part: int, parts: int, alphabet: int = ALPHABET_NT):
+    """-> (code rows of the records that start in this part's byte range, pending error or None, usable)"""
+    ptr, n, L, pending, usable = C.c_void_p(), C.c_uint64(0), C.c_uint32(0), C.c_int(0), C.c_int(0)
+    check(lib().smafa_fastx_load_part(os.fsencode(path), alphabet, part, parts, C.byref(ptr), C.byref(n), C.byref(L),
+                                      C.byref(pending), C.byref(usable)))
+    err = None
+    if pending.value != _lib.OK:
+        msg = lib().smafa_last_error().decode(errors="replace")
+        err = (SmafaPanic if pending.value == _lib.ERR_PANIC else SmafaError)(pending.value, msg)
+    try:
+        size = n.value * L.value
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(max(size, 1),))[:size].copy() if ptr else np.zeros(0, np.uint8)
+    finally:
+        lib().smafa_free(ptr)
+    return arr.reshape(n.value, L.value) if L.value else arr.reshape(0, 0), err, bool(usable.value)
+
+
 def write_db(path: str, codes: np.ndarray, alphabet: int = ALPHABET_NT) -> None:
     c = np.ascontiguousarray(codes, dtype=np.uint8)
     check(lib().smafa_dbfile_write(os.fsencode(path), alphabet, c.ctypes.data, c.shape[0], c.shape[1]))

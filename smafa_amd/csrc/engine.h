@@ -22,6 +22,8 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
 // Bring the HIP runtime and the device context up (a few hundred ms the first time in a process).  The drivers call it
 // on a helper thread while they read and decode their input; failures are ignored here — the first real call reports.
 void warm_device(int device);
+// device time of the scan kernels of every host-buffer scan on this handle so far, and their launches
+void db_life_stats(const smafa_db *db, double *kernel_ms, uint64_t *launches);
 // Forget the subjects but keep the handle's device memory, stream and scratch (cluster's per-batch candidate store).
 int db_clear(smafa_db *db);
 class PackedStore;
@@ -37,6 +39,10 @@ struct SubjectRows {
 int select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint64_t n_subjects,
                 const SubjectRows &subjects, uint32_t max_div, uint32_t max_num_hits, uint32_t limit_per_sequence,
                 std::vector<smafa_hit> &rows);
+// "{q_base + query}\t{subject}\t{distance}\t{subject string}\n" per row (src/lib.rs:292,310) to fd (host/drivers.cpp)
+int write_rows_text(const smafa_hit *rows, size_t n, const SubjectRows &subjects, int alphabet, uint32_t q_base, int fd);
+// IO / format failures of the FASTX layer become the reference's .expect(what) panic (host/drivers.cpp)
+int expect_fastx(int rc, const char *what);
 // a store handle whose HBM image comes straight from a mapped packed store file
 int db_load_packed(smafa_db **out, int device, const PackedStore &pk);
 

@@ -79,6 +79,8 @@ struct smafa_db {
     // path are several scans): smafa_last_call_stats
     float call_ms = 0.f;
     uint32_t call_launches = 0, call_scans = 0;
+    double life_ms = 0.0;        // ... and over the handle's life (the cluster driver's debug line)
+    uint64_t life_launches = 0;
     // smafa_scan_each: the K one-query launches captured once as a HIP graph and replayed
     hipGraphExec_t each_graph = nullptr;
     struct EachKey { const void *qs, *hits, *counts; uint64_t cap, nq, generation; uint32_t max_div; int zone; bool filter; } each_key{};
@@ -803,6 +805,8 @@ static void note_call_scan(smafa_db *db) {
     db->call_launches += db->last_launches;
     float ms = 0.f;
     if (db->timed && hipEventElapsedTime(&ms, db->ev0, db->ev1) == hipSuccess) db->call_ms += ms;
+    db->life_ms += ms;
+    db->life_launches += db->last_launches;
 }
 
 static bool hit_less(const smafa_hit &x, const smafa_hit &y) {
@@ -938,6 +942,11 @@ static int collect_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_
         return collect_range(db, qs, q_begin, q_end, max_div, max_num_hits, out);
     }
     return fetch_rows(db, count, q_begin, q_end, out);
+}
+
+void db_life_stats(const smafa_db *db, double *kernel_ms, uint64_t *launches) {
+    *kernel_ms = db ? db->life_ms : 0.0;
+    *launches = db ? db->life_launches : 0;
 }
 
 void warm_device(int device) {

@@ -72,6 +72,8 @@ void append_decoded(std::string &s, int alphabet, const uint8_t *codes, uint32_t
     for (uint32_t i = 0; i < L; i++) s[base + i] = letter_of(alphabet, codes[i]);
 }
 
+}  // namespace
+
 // "{query}\t{subject}\t{distance}\t{subject string}\n" per row (src/lib.rs:292,310), written to fd in order.  Big row
 // lists are formatted by several threads, each into its own buffer over a contiguous slice of the rows.
 int write_rows_text(const smafa_hit *rows, size_t n, const SubjectRows &subjects, int alphabet, uint32_t q_base, int fd) {
@@ -133,6 +135,8 @@ int expect_fastx(int rc, const char *what) {
     const std::string msg = smafa_last_error();
     return set_error(SMAFA_ERR_PANIC, "%s: %s", what, msg.c_str());
 }
+
+namespace {
 
 struct DbGuard {
     smafa_db *db = nullptr;
@@ -773,6 +777,14 @@ static int cluster_run(const char *input_fasta, uint32_t max_divergence, int out
 
         log_line(2, "%zu batches: scans vs old centroids %.2f s, candidate scans %.2f s, sequential pass %.2f s, "
                     "centroid appends %.2f s", n_batches, t_old, t_cand, t_seq, t_append);
+        {
+            double ms_a = 0, ms_b = 0;
+            uint64_t la = 0, lb = 0;
+            db_life_stats(centroids.db, &ms_a, &la);
+            db_life_stats(cand.db, &ms_b, &lb);
+            log_line(2, "scan kernels %.1f ms over %llu launches (vs old centroids %.1f ms, vs candidates %.1f ms)", ms_a + ms_b,
+                     (unsigned long long)(la + lb), ms_a, ms_b);
+        }
         // src/cluster.rs:79-84.  Every line is "raw record \t centroid string \n" = 2L + 2 bytes, so line k of the
         // output sits at byte k * (2L + 2): blocks of lines are formatted by all threads and written in order.
         if (rank == 0) {

@@ -554,6 +554,54 @@ bool load_parallel(const uint8_t *d, size_t total, Progress &pr, bool fastq, int
 
 }  // namespace
 
+// One part of a plain FASTA/FASTQ file (see fastx.h).  cut(i) = the first record start at or after byte total * i / parts
+// (snap_record_start: the rule the threaded loader cuts by); part p owns the records that start in [cut(p), cut(p + 1)).
+int load_records_part(const char *path, int alphabet, unsigned part, unsigned parts, BulkRecords &out, bool *usable) {
+    out = BulkRecords();
+    *usable = false;
+    if (parts == 0 || part >= parts) return set_error(SMAFA_ERR_INVALID, "part %u of %u", part, parts);
+    Mapped file;
+    if (!file.open(path)) return SMAFA_OK;  // unreadable or empty: the whole-file loader words the failure
+    const bool gz = file.len >= 2 && file.p[0] == 0x1f && file.p[1] == 0x8b;
+    if (gz || (file.p[0] != '>' && file.p[0] != '@')) return SMAFA_OK;  // a gzip stream cannot be cut
+    const bool fastq = file.p[0] == '@';
+    const size_t total = file.len;
+    auto cut = [&](unsigned i) -> size_t {
+        if (i == 0) return 0;
+        if (i >= parts) return total;
+        const size_t b = snap_record_start(file.p, total, total, (size_t)((unsigned __int128)total * i / parts), fastq);
+        return b == kUndecided ? total : b;
+    };
+    const size_t lo = cut(part), hi = cut(part + 1);
+    if (hi > lo && hi - lo >= (32u << 20)) {  // a big part: this process's threads share it (the part is a file of its own)
+        const unsigned T = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        Progress pr;
+        pr.publish(hi - lo, true);
+        if (T >= 2 && load_parallel(file.p + lo, hi - lo, pr, fastq, alphabet, false, T, out)) {
+            *usable = true;
+            return SMAFA_OK;
+        }
+        out = BulkRecords();
+    }
+    ChunkOut c;
+    c.lo = lo;
+    c.hi = hi;
+    c.codes.reserve(hi - lo);
+    parse_chunk(file.p, total, total, fastq, alphabet, false, c);
+    // the part must end exactly where the next one begins (else a cut was not a record start: nobody can use the parts);
+    // a malformed record is worded by the one-thread reader, as in the threaded loader
+    if (c.err_kind == 4 || (!c.err_kind && c.end_pos != hi)) return SMAFA_OK;
+    out.L = c.have_L ? c.L : 0;
+    out.n = c.good;
+    out.codes.swap(c.codes);
+    out.err_kind = c.err_kind;
+    out.err_len = c.err_len;
+    out.err_msg = c.err_msg;
+    if (c.have_L && c.L == 0 && c.good == 0 && !c.err_kind) out.err_kind = 3;
+    *usable = true;
+    return SMAFA_OK;
+}
+
 uint64_t fastx_expanded_size(const char *path) {
     Mapped f;
     if (!f.open(path)) return 0;

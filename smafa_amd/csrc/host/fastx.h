@@ -67,6 +67,13 @@ struct BulkRecords {
     std::string err_msg;
 };
 int load_records_bulk(const char *path, int alphabet, bool want_raw, BulkRecords &out);
+// One PART of a plain (not gzip) FASTA/FASTQ file, for hosts that shard a query file over several processes (one per
+// GPU): the records that START in [cut(part), cut(part + 1)), cut(i) = the first record start at or after byte
+// size * i / parts — every process computes the same cuts, so the parts partition the records in file order and each
+// process reads only its own bytes.  `out` as load_records_bulk fills it (L = the length of the PART's first record; the
+// caller compares it with the store's).  *usable = false: this file cannot be taken in parts (gzip, not FASTX, a cut that
+// did not hold, a malformed record) — every process must then load the whole file (load_records_bulk) instead.
+int load_records_part(const char *path, int alphabet, unsigned part, unsigned parts, BulkRecords &out, bool *usable);
 // Size of the file's contents once decompressed (gzip: the ISIZE trailer; plain: the file size; 0: cannot tell) — how the
 // drivers decide between streaming a query file and bulk-loading it with all threads.
 uint64_t fastx_expanded_size(const char *path);

@@ -133,18 +133,147 @@ def cluster_sharded(input_fasta: str, max_divergence: int, out_fd: int = 1, alph
                                                 rank, world, cb, None))
 
 
+class QuerySession:
+    """smafa_qsession_*: the DB opened once by this process (a packed store file is mapped and copied to HBM — no decode,
+    no host code rows), shares of a query file answered, rows printed by rank 0."""
+
+    def __init__(self, db_path: str, device: int):
+        import ctypes as C
+
+        from . import _lib
+
+        self._lib, self._C = _lib, C
+        self._h = C.c_void_p()
+        api.check(_lib.lib().smafa_qsession_open(C.byref(self._h), os.fsencode(db_path), int(device)))
+
+    def scan_part(self, query_fasta, max_divergence, max_num_hits, limit_per_sequence, part, parts, whole_file):
+        """-> (rows numbered from 0 within the share, records answered, records in front or None, pending error or None,
+        retry_whole)"""
+        C, l = self._C, self._lib.lib()
+        rows_p, n_rows, n_q, n_before = C.c_void_p(), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        pending, retry = C.c_int(0), C.c_int(0)
+        opt = lambda v: self._lib.NONE if v is None else int(v)
+        api.check(l.smafa_qsession_scan_part(self._h, os.fsencode(query_fasta), opt(max_divergence), opt(max_num_hits),
+                                             opt(limit_per_sequence), part, parts, 1 if whole_file else 0, C.byref(rows_p),
+                                             C.byref(n_rows), C.byref(n_q), C.byref(n_before), C.byref(pending), C.byref(retry)))
+        err = None
+        if pending.value != self._lib.OK:
+            err = (pending.value, l.smafa_last_error().decode(errors="replace"))
+        try:
+            n = n_rows.value
+            rows = np.zeros(n, dtype=api.HIT_DTYPE)
+            if n:
+                C.memmove(rows.ctypes.data, rows_p, n * 12)
+        finally:
+            l.smafa_free(rows_p)
+        before = None if n_before.value == 0xFFFFFFFFFFFFFFFF else int(n_before.value)
+        return rows, int(n_q.value), before, err, bool(retry.value)
+
+    def write(self, rows: np.ndarray, out_fd: int) -> None:
+        rows = np.ascontiguousarray(rows, dtype=api.HIT_DTYPE)
+        api.check(self._lib.lib().smafa_qsession_write(self._h, rows.ctypes.data, len(rows), out_fd))
+
+    def close(self):
+        if self._h:
+            self._lib.lib().smafa_qsession_close(self._h)
+            self._h = self._C.c_void_p()
+
+
+def _raise(code: int, msg: str):
+    from . import _lib
+
+    raise (api.SmafaPanic if code == _lib.ERR_PANIC else api.SmafaError)(code, msg)
+
+
+def _query_sharded_native(db_path, query_fasta, max_divergence, max_num_hits, limit_per_sequence, out_fd, dist, device, gpu):
+    """The product path: every rank opens the DB itself (a packed store file: mmap + copies), parses ONLY its byte range of
+    the query file, scans and selects on its GPU; what is exchanged is one small state vector per rank, then one gather of
+    the finished row lists to rank 0, which prints them (subject strings decoded for the hit rows only)."""
+    import torch
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+
+    def exchange(failure, retry, nq, pending):
+        """-> per-rank [failed, retry, records answered, pending code]; any failure's text is passed around and raised on
+        EVERY rank (nobody is left waiting in the gather)"""
+        mine = torch.tensor([1 if failure else 0, 1 if retry else 0, nq, pending[0] if pending else 0], dtype=torch.int64, device=device)
+        parts = [torch.zeros(4, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        state = [[int(x) for x in p.cpu().tolist()] for p in parts]
+        if any(st[0] for st in state):
+            text = (str(failure).encode() if failure else b"")[:2000]
+            code = np.array([failure.code if failure else 0], dtype=np.int32).tobytes()
+            blob = allgather_bytes(np.frombuffer(code + len(text).to_bytes(4, "little") + text, dtype=np.uint8), dist, device)
+            off = 0
+            for st in state:  # blocks in rank order; the first failing rank's error is everybody's
+                c = int(np.frombuffer(blob[off:off + 4].tobytes(), dtype=np.int32)[0])
+                n = int.from_bytes(blob[off + 4:off + 8].tobytes(), "little")
+                if st[0]:
+                    _raise(c, blob[off + 8:off + 8 + n].tobytes().decode(errors="replace"))
+                off += 8 + n
+        return state
+
+    sess, failure = None, None
+    rows, nq, before, pending, retry = np.zeros(0, dtype=api.HIT_DTYPE), 0, None, None, False
+    try:
+        sess = QuerySession(db_path, gpu)
+        rows, nq, before, pending, retry = sess.scan_part(query_fasta, max_divergence, max_num_hits, limit_per_sequence,
+                                                          rank, world, False)
+    except api.SmafaError as e:
+        failure = e
+    try:
+        state = exchange(failure, retry, nq, pending)
+        whole = any(st[1] for st in state)
+        if whole:  # gzip input, or a cut that did not hold: everybody parses the whole file and takes its block by count
+            try:
+                rows, nq, before, pending, retry = sess.scan_part(query_fasta, max_divergence, max_num_hits,
+                                                                  limit_per_sequence, rank, world, True)
+            except api.SmafaError as e:
+                failure = e
+            state = exchange(failure, False, nq, pending)
+        if whole:
+            offset, first_bad = before, None  # the pending error is the same on every rank; every share is in front of it
+        else:
+            offset = sum(st[2] for st in state[:rank])
+            bad = [r for r, st in enumerate(state) if st[3]]
+            first_bad = bad[0] if bad else None
+            if first_bad is not None and rank > first_bad:  # the reference never got this far (src/lib.rs:232-318)
+                rows = rows[:0]
+        rows = rows.copy()
+        rows["query"] += offset
+        all_rows = gather_rows(rows, dist, device)
+        if rank == 0:
+            sess.write(all_rows, out_fd)
+        # the record the reference's loop fails on, reported after the rows in front of it — by every rank
+        if whole and pending is not None:
+            _raise(*pending)
+        if first_bad is not None:
+            text = pending[1].encode()[:2000] if (pending and rank == first_bad) else b""
+            blob = allgather_bytes(np.frombuffer(text, dtype=np.uint8), dist, device)
+            _raise(state[first_bad][3], blob.tobytes().decode(errors="replace"))
+    finally:
+        if sess is not None:
+            sess.close()
+
+
 def query_sharded(db_path: str, query_fasta: str, max_divergence: Optional[int] = None,
                   max_num_hits: Optional[int] = None, limit_per_sequence: Optional[int] = None, out_fd: int = 1,
                   scan_fn: Optional[ScanFn] = None, dist=None, device=None, gpu: Optional[int] = None) -> None:
     """`smafa query` across the ranks of an initialised process group (src/lib.rs:198-325 semantics).
 
-    `scan_fn(subject_codes, query_codes, max_divergence, k)` must return every row within the bounds ordered
-    by (query, dist, subject); the default is the HIP scanner on this rank's GPU.  (Tests on CPU-only hosts
-    inject a checker here; the product never does.)
+    Default (scan_fn None): the product path — smafa_qsession_* on this rank's GPU: the DB opened once per rank without
+    host code rows for a packed store, only this rank's byte range of the query file parsed, rows gathered on rank 0.
+    `scan_fn(subject_codes, query_codes, max_divergence, k)` (every row within the bounds ordered by (query, dist,
+    subject)) replaces the device scan for tests on CPU-only hosts, which then exercise the sharding and the gather over
+    host code rows; the product never passes one.
     """
     if dist is None:
         import torch.distributed as dist  # type: ignore[no-redef]
     world, rank = dist.get_world_size(), dist.get_rank()
+    if scan_fn is None:  # the product path
+        return _query_sharded_native(db_path, query_fasta, max_divergence, max_num_hits, limit_per_sequence, out_fd, dist,
+                                     device, int(os.environ.get("LOCAL_RANK", rank)) if gpu is None else gpu)
+    # ---- test scaffolding (CPU-only hosts): the same sharding and gather with an injected scanner over host code rows
     alphabet, subj = api.read_db(db_path)
     # the queries in front of a bad record are answered before the failure is reported, as the reference's loop does
     queries, pending = api.load_fastx_partial(query_fasta, alphabet)

@@ -74,14 +74,17 @@ def main():
         return
     fd = os.open(a.out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC) if dist.get_rank() == 0 else -1
     scan_fn = oracle_scan
-    if a.hip:  # product scanner; every rank shares GPU 0 of the one-GPU test box
-        scan_fn = sdist.HipScanner(smafa_amd.read_db(a.db)[0], 0)
+    if a.hip:  # the product path (smafa_qsession_*); every rank shares GPU 0 of the one-GPU test box
+        scan_fn = None
     try:
         sdist.query_sharded(a.db, a.queries, a.max_divergence, a.max_num_hits, a.limit_per_sequence,
-                            out_fd=fd if fd >= 0 else 1, scan_fn=scan_fn, dist=dist)
+                            out_fd=fd if fd >= 0 else 1, scan_fn=scan_fn, dist=dist, gpu=0)
     except smafa_amd.SmafaPanic as e:  # the reference's panic: message on stderr, exit 101 (like the CLI)
         sys.stderr.write(str(e) + "\n")
         sys.exit(101)
+    except smafa_amd.SmafaError as e:  # an Err out of main: exit 1
+        sys.stderr.write(str(e) + "\n")
+        sys.exit(1)
     finally:
         if fd >= 0:
             os.close(fd)

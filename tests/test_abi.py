@@ -441,3 +441,53 @@ def test_packed_store_file_written_without_a_gpu(tmp_path, alphabet, n_letters, 
     for name, edit in cases.items():
         with pytest.raises(smafa_amd.SmafaError):
             smafa_amd.read_db(damaged(edit, name))
+
+
+@pytest.mark.parametrize("kind", ["fasta", "fasta_multiline_crlf", "fastq", "fastq_at_quality"])
+def test_query_file_parts_partition_the_records(tmp_path, kind):
+    """smafa_fastx_load_part (what one process per GPU reads of a query file): for any number of parts the parts'
+    records, concatenated in part order, are the whole file's records; gzip input is refused (usable = False)"""
+    import gzip
+
+    rng = np.random.default_rng(3)
+    n, L = 997, 37
+    s = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    recs = []
+    for i, r in enumerate(letters[s]):
+        seq = r.tobytes()
+        if kind == "fasta":
+            recs.append(b">r%d some words\n%s\n" % (i, seq))
+        elif kind == "fasta_multiline_crlf":
+            recs.append(b">r%d\r\n%s\r\n%s\r\n" % (i, seq[:20], seq[20:]))
+        else:
+            qual = bytes(rng.integers(33, 74, size=L, dtype=np.uint8))
+            if kind == "fastq_at_quality":
+                qual = b"@" + qual[1:]  # a quality line that begins like a header: the cut rule must not take it for one
+            recs.append(b"@r%d\n%s\n+\n%s\n" % (i, seq, qual))
+    path = str(tmp_path / "q.fx")
+    open(path, "wb").write(b"".join(recs))
+    whole = smafa_amd.load_fastx(path)
+    assert whole.tobytes() == s.tobytes()
+    for parts in (1, 2, 3, 7, 64, 2000):
+        got, counts = [], []
+        for p in range(parts):
+            rows, err, usable = smafa_amd.load_fastx_part(path, p, parts)
+            assert usable and err is None
+            counts.append(len(rows))
+            if len(rows):
+                got.append(rows)
+        assert np.concatenate(got).tobytes() == s.tobytes(), (kind, parts)
+        if parts <= 64:
+            assert max(counts) - min(counts) <= 2 + n // parts // 4, counts  # shares of nearly equal size
+    # a bad byte in the middle: the part that holds it reports it, with the rows in front of it
+    bad = b"".join(recs[:500]) + recs[500].replace(b"A", b"E", 1) + b"".join(recs[501:])
+    open(path, "wb").write(bad)
+    rows, err, usable = smafa_amd.load_fastx_part(path, 1, 2)
+    first = len(smafa_amd.load_fastx_part(path, 0, 2)[0])
+    assert usable and isinstance(err, smafa_amd.SmafaPanic) and "cannot be interpreted as nucleotide" in str(err)
+    assert first + len(rows) == 500
+    gz = str(tmp_path / "q.fx.gz")
+    with gzip.open(gz, "wb") as g:
+        g.write(b"".join(recs))
+    assert smafa_amd.load_fastx_part(gz, 0, 2)[2] is False

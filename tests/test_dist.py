@@ -47,6 +47,14 @@ def launch(world, worker_args):
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
 
 
+def exit_code_of_ranks(r):
+    """torch.distributed.run exits 1 whatever its workers returned; their own status is in its failure report"""
+    import re
+
+    codes = set(int(m) for m in re.findall(r"exitcode\s*:\s*(-?\d+)", r.stderr))
+    return codes.pop() if len(codes) == 1 else (0 if r.returncode == 0 else sorted(codes))
+
+
 def run_world(world, db, qf, out, flags, hip=False):
     return launch(world, ["--db", db, "--queries", qf, "--out", out, *flags] + (["--hip"] if hip else []))
 
@@ -113,6 +121,67 @@ def test_sharded_query_hip_scanner_equals_oracle(tmp_path):
     r = run_world(2, db, qf, out, flags, hip=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(out).read() == want.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_sharded_query_parts_packed_store_gzip_and_bad_records(tmp_path, world):
+    """the product path of smafa_amd.dist (smafa_qsession_*): every rank opens the DB itself (version-2 file, then the packed
+    store file: no host code rows), parses only its byte range of the query file (a gzip file: everybody falls back to the
+    whole file), and rank 0 prints — stdout and exit status of the oracle CLI in every case, incl. a bad record in the
+    first and in the last rank's share (rows behind a bad record are never printed)"""
+    import gzip
+
+    db, qf = make_inputs(tmp_path, n=3000, q=211, L=60)
+    flags = ["--max-divergence", "6", "--max-num-hits", "3"]
+    want = oracle.run_cli("query", "-d", db, "-q", qf, *flags)
+    assert want.returncode == 0 and want.stdout
+    out = str(tmp_path / "out.tsv")
+    r = run_world(world, db, qf, out, flags, hip=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(out).read() == want.stdout
+    # the packed store file (what `makedb --packed` writes)
+    packed = str(tmp_path / "db.packed")
+    alphabet, codes = smafa_amd.read_db(db)
+    st = smafa_amd.SubjectStore(60, alphabet, 0)
+    st.push(codes)
+    st.save(packed)
+    st.close()
+    for f in (flags, [], ["--max-num-hits", "4", "--limit-per-sequence", "1"]):
+        w = oracle.run_cli("query", "-d", db, "-q", qf, *f)
+        r = run_world(world, packed, qf, out, f, hip=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert open(out).read() == w.stdout, f
+    # gzip queries: no byte ranges — every rank takes the whole file and its block by count
+    gz = str(tmp_path / "q.fna.gz")
+    with gzip.open(gz, "wb") as g:
+        g.write(open(qf, "rb").read())
+    r = run_world(world, packed, gz, out, flags, hip=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(out).read() == want.stdout
+    # a bad byte in the first share / in the last share
+    raw = open(qf, "rb").read().split(b">")
+    for victim in (20, 200):
+        bad = list(raw)
+        bad[victim + 1] = bad[victim + 1][:-5] + b"E" + bad[victim + 1][-4:]
+        bf = str(tmp_path / ("bad%d.fna" % victim))
+        open(bf, "wb").write(b">".join(bad))
+        w = oracle.run_cli("query", "-d", db, "-q", bf, *flags)
+        assert w.returncode == 101 and w.stdout
+        r = run_world(world, packed, bf, out, flags, hip=True)
+        assert exit_code_of_ranks(r) == 101, (r.returncode, r.stderr[-2000:])
+        assert open(out).read() == w.stdout, victim
+        assert r.stderr.count("cannot be interpreted as nucleotide") >= world, r.stderr[-2000:]
+    # an input-independent panic with an empty share on one rank: every rank fails alike, nobody waits in the gather
+    one = str(tmp_path / "one.fna")
+    open(one, "wb").write(b">" + raw[1])
+    r = run_world(world, packed, one, out, ["--limit-per-sequence", "1"], hip=True)
+    assert exit_code_of_ranks(r) == 101 and r.stderr.count("limit_per_sequence is implemented unless max_num_hits > 1") >= world, r.stderr[-3000:]
+    # a missing query file is a panic (exit 101), a missing DB an Err (exit 1) — on every rank
+    r = run_world(world, packed, str(tmp_path / "nope.fna"), out, flags, hip=True)
+    assert exit_code_of_ranks(r) == 101, r.stderr[-1000:]
+    r = run_world(world, str(tmp_path / "nope.db"), qf, out, flags, hip=True)
+    assert exit_code_of_ranks(r) == 1, r.stderr[-1000:]
 
 
 @pytest.mark.parametrize("world", [2, 3])

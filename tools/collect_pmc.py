@@ -53,6 +53,29 @@ def counter_rows(out_dir):
     return rows
 
 
+def per_call(rows, calls):
+    """counter totals over EVERY scan kernel dispatch of the run, divided by the number of identical calls the run made
+    (mode besthit: one smafa_scan_hits call is a ladder of scans; cluster: calls = 1, the whole run)"""
+    mine = [r for r in rows if "smafa::scan_" in r["Kernel_Name"]]
+    if not mine:
+        return {}, 0, 0.0, {}
+    disp, by_kernel = {}, {}
+    for r in mine:
+        d = disp.setdefault(r["Dispatch_Id"], {"_k": r["Kernel_Name"]})
+        d[r["Counter_Name"]] = float(r["Counter_Value"])
+        d["_ns"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    names = sorted({k for d in disp.values() for k in d if not k.startswith("_")})
+    tot = {n: sum(d.get(n, 0.0) for d in disp.values()) / calls for n in names}
+    ms = sum(d["_ns"] for d in disp.values()) / calls / 1e6
+    for d in disp.values():
+        k = by_kernel.setdefault(d["_k"].split("(")[0], {"dispatches": 0, "ms": 0.0})
+        k["dispatches"] += 1.0 / calls
+        k["ms"] += d["_ns"] / 1e6 / calls
+        for n in names:
+            k[n] = k.get(n, 0.0) + d.get(n, 0.0) / calls
+    return tot, len(disp), ms, by_kernel
+
+
 def per_launch(rows, kernel_sub):
     """average counter value per dispatch of the kernel, over its full-size dispatches"""
     mine = [r for r in rows if kernel_sub in r["Kernel_Name"]]
@@ -75,6 +98,9 @@ def main():
     ap.add_argument("--tag", default="r02_prof")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--skip-stats", action="store_true")
+    ap.add_argument("--passes", default="sq_a,sq_b,fetch,write", help="counter passes to run (sq_a carries SQ_INSTS_VALU)")
+    ap.add_argument("--cluster", action="store_true",
+                    help="profile `smafa cluster -d 5 --alphabet aa` on BASELINE configs[4]'s 5M records instead of bench.py")
     ap.add_argument("bench_args", nargs="*", help="extra bench.py flags (after --)")
     a = ap.parse_args()
     out = os.path.join(ROOT, "gpurun_out", a.tag)
@@ -83,6 +109,8 @@ def main():
     bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "2", "--no-cpu-baseline",
              "--no-stream", *a.bench_args]
     prof = "/opt/rocm/bin/rocprofv3"
+    if a.cluster:
+        return cluster_main(a, out, prof)
 
     record = {"command": " ".join(bench[1:]).replace(ROOT + "/", "")}
     if not a.skip_stats:
@@ -96,8 +124,9 @@ def main():
         for path in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
             with open(path, newline="") as f:
                 record["kernel_stats"] = [r for r in csv.DictReader(f)][:12]
-    passes = [("sq_a", SQ_A), ("sq_b", SQ_B), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])]
-    merged, n_disp, kernel, cfg, ms_prof = {}, {}, None, None, {}
+    passes = [p for p in (("sq_a", SQ_A), ("sq_b", SQ_B), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]))
+              if p[0] in a.passes.split(",")]
+    merged, n_disp, kernel, cfg, ms_prof, by_kernel = {}, {}, None, None, {}, {}
     for name, counters in passes:
         d = os.path.join(out, name)
         rc = run([prof, "--pmc", *counters, "--kernel-trace", "-d", d, "-o", name, "--output-format", "csv", "--", *bench],
@@ -110,7 +139,11 @@ def main():
         kernel = line["roofline"]["kernel"].split(" (")[0]  # (a note like " (zone level on)" is not part of the symbol)
         cfg = line["config"]
         record["build_id"] = line.get("build_id")
-        avg, nd, ms = per_launch(counter_rows(d), kernel.replace("smafa::", ""))
+        if cfg.get("mode") == "besthit":  # one call = a ladder of scans: totals over all scan kernels per call
+            avg, nd, ms, bk = per_call(counter_rows(d), line["calls_total"])
+            by_kernel[name] = bk
+        else:
+            avg, nd, ms = per_launch(counter_rows(d), kernel.replace("smafa::", ""))
         merged.update(avg)
         n_disp[name] = nd
         ms_prof[name] = ms
@@ -122,7 +155,10 @@ def main():
     record.update({
         "kernel": kernel,
         "config": {"db_rows": cfg["db_rows"], "seq_len": cfg["seq_len"], "queries": cfg["queries_per_gpu"],
-                   "max_div": cfg["max_divergence"], "alphabet": cfg["alphabet"], "store": cfg.get("store", "uniform")},
+                   "max_div": cfg["max_divergence"], "alphabet": cfg["alphabet"], "store": cfg.get("store", "uniform"),
+                   "n_frac": cfg.get("n_frac", 0.0), "prefilter": cfg.get("prefilter", 1), "mode": cfg.get("mode", "scan"),
+                   "far_frac": cfg.get("far_frac", 0.5)},
+        "by_kernel_per_call": by_kernel.get("sq_a"),
         "per_launch": merged,
         "dispatches_averaged": n_disp,
         "kernel_ms_under_profiler": ms_prof,
@@ -160,6 +196,53 @@ def main():
     print("wrote", path)
     print(json.dumps({k: record[k] for k in ("kernel", "config", "build_id")}))
     print(json.dumps(record.get("derived", {}), indent=1))
+    return 0
+
+
+def cluster_main(a, out, prof):
+    """counter totals over every scan kernel of ONE `smafa cluster` run on BASELINE configs[4]'s records (the program after
+    `--` is the CLI binary itself)"""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+
+    from smafa_amd import synth
+
+    fasta = "/tmp/r03_cluster_5M.faa"
+    if not os.path.exists(fasta):
+        recs = synth.cluster_records(100_000, 50, 60, 1, seed=4, max_subs=4)
+        letters = np.array([ord("A") + i for i in range(26)] + [ord("*"), ord("-")], dtype=np.uint8)
+        n, L = recs.shape
+        ids = np.char.zfill(np.arange(n).astype("U8"), 8).astype("S8")
+        rec = np.empty((n, 1 + 8 + 1 + L + 1), dtype=np.uint8)
+        rec[:, 0], rec[:, 9], rec[:, 10 + L] = ord(">"), 10, 10
+        rec[:, 1:9] = np.frombuffer(ids.tobytes(), dtype=np.uint8).reshape(n, 8)
+        rec[:, 10:10 + L] = letters[recs]
+        rec.tofile(fasta)
+    cli = [os.path.join(ROOT, "smafa_amd", "bin", "smafa"), "cluster", "-i", fasta, "-d", "5", "--alphabet", "aa", "-v"]
+    bid = subprocess.run(["python3", "-c", "import smafa_amd; print(smafa_amd.build_id())"], cwd=ROOT, capture_output=True, text=True)
+    record = {"command": "smafa cluster -i <5M x 60 aa, seed 4> -d 5 --alphabet aa", "build_id": bid.stdout.strip(),
+              "kernel": "all scan kernels of the run", "config": {"mode": "cluster", "records": 5_000_000}}
+    merged, ms_prof, bk_all = {}, {}, None
+    for name, counters in (("sq_a", SQ_A), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+        d = os.path.join(out, "cluster_" + name)
+        with open(os.path.join(out, "cluster_" + name + ".log"), "w") as f:
+            rc = subprocess.run([prof, "--pmc", *counters, "--kernel-trace", "-d", d, "-o", name, "--output-format", "csv", "--", *cli],
+                                stdout=subprocess.DEVNULL, stderr=f, cwd=ROOT).returncode
+        print("cluster", name, "pass rc", rc, flush=True)
+        tot, nd, ms, bk = per_call(counter_rows(d), 1)
+        merged.update(tot)
+        ms_prof[name] = ms
+        if name == "sq_a":
+            bk_all = bk
+            record["dispatches"] = nd
+    if "FETCH_SIZE" in merged:
+        merged["hbm_bytes"] = merged["FETCH_SIZE"] * 1024.0 * 2.0 + merged.get("WRITE_SIZE", 0.0) * 1024.0
+    record.update({"per_launch": merged, "kernel_ms_under_profiler": ms_prof, "by_kernel_per_call": bk_all})
+    if merged.get("SQ_INSTS_VALU") and ms_prof.get("sq_a"):
+        record["derived"] = {"lane_ops_per_s": merged["SQ_INSTS_VALU"] * 64.0 / (ms_prof["sq_a"] * 1e-3)}
+    path = os.path.join(out, "pmc_record.json")
+    json.dump(record, open(path, "w"), indent=1)
+    print("wrote", path)
     return 0
 
 
