@@ -824,7 +824,17 @@ constexpr int kFewTiles = SMAFA_FEW_TILES;  // wave tiles per wave in scan_zone_
 // (v_readlane -> scalar-operand xor -> bcnt -> or -> cmp -> branch), so one more resident wave pays as long as the hot
 // path does not spill: measured (profiles/r02_zone_variants.txt) aa 60 columns 2.55 -> 2.45 ms at 5 waves (3.06 at 6:
 // spills), nt 60 columns 6.38 -> 5.91 ms at 6 waves.  What caps it is the dense fallback's tile (PS * W vectors).
-__host__ __device__ constexpr int zone_min_waves(int ps, int w) { return ps * w <= 4 ? 6 : ps * w <= 10 ? 5 : 4; }
+#ifndef SMAFA_ZONE_WAVES_10
+#define SMAFA_ZONE_WAVES_10 5  // waves per SIMD asked for where a tile holds 5..10 vectors (aa 60 columns: 10)
+#endif
+#ifndef SMAFA_ZONE_SGPR_ZONE
+#define SMAFA_ZONE_SGPR_ZONE 1  // 1: word 0's zone words of the wave's tiles live in scalar registers (those of tiles 1.. end up
+                                // in spilled VGPR lanes); 0: they are read out of their VGPR lane where they are used
+#endif
+#ifndef SMAFA_ZONE_NLIVE
+#define SMAFA_ZONE_NLIVE 1  // 1: "tile slot t is inside the range" is ONE scalar (the number of live slots) instead of T lane masks
+#endif
+__host__ __device__ constexpr int zone_min_waves(int ps, int w) { return ps * w <= 4 ? 6 : ps * w <= 10 ? SMAFA_ZONE_WAVES_10 : 4; }
 
 // FIXED: one bound for every query (a.thr == NULL, the plain --max-divergence scan).  The chunks are then staged by
 // LDS-DMA (global_load_lds_dwordx4: no register hop — the prefetch registers of the other form were being spilled
@@ -855,6 +865,9 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
     const uint32_t qblock = blockIdx.x / a.n_wg_tiles;
     const uint32_t tile0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.tile_begin + (wg_tile * WGW + wave) * T));
     const bool active = tile0 < a.tile_end;
+    // tile slots of this wave that lie inside the range: one scalar (T lane masks, kept across the chunk loop, were being
+    // spilled into VGPR lanes)
+    const uint32_t n_live = active ? min((uint32_t)T, a.tile_end - tile0) : 0u;
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
     const uint32_t q1 = min(q0 + a.qb_size, a.q_end);
 
@@ -863,7 +876,7 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
     auto load_filter = [&]() {
 #pragma unroll
         for (int t = 0; t < T; t++) {
-            const bool live = tile0 + t < a.tile_end;
+            const bool live = SMAFA_ZONE_NLIVE ? (uint32_t)t < n_live : tile0 + t < a.tile_end;
             f0[t] = planes[(size_t)(live ? tile0 + t : a.tile_begin) * (PS * W * 64) + (FP * W) * 64 + lane];
         }
     };
@@ -970,14 +983,21 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
                 if (lane < nqc) head = stage[buf][lane * RV];
                 const uint32_t hq0 = head.x, hq1 = W > 1 ? head.y : 0u;
                 const uint32_t hnu = lane < nqc ? (FIXED ? nu0 : nu_lds[buf][lane]) : 0u;
+                // (opaque copy: the comparisons against it are redone per chunk — one s_cmp each — instead of being hoisted
+                // out of the chunk loop as T lane masks that then live in spilled VGPR lanes)
+                uint32_t nl = n_live;
+                asm volatile("" : "+s"(nl));
+                if (!SMAFA_ZONE_SGPR_ZONE) asm volatile("" : "+v"(vz.x), "+v"(vz.y));  // (read out of vz where they are used)
                 // Tile by tile, unrolled (the rare levels' address math stays inside their branch thanks to the opaque
                 // tile number below; a run-time tile loop cost 4 % on aa and 27 % on nt at bound 3 in per-tile
                 // bookkeeping — profiles/r02_zone_variants.txt).
 #pragma unroll
                 for (uint32_t t = 0; t < (uint32_t)T; t++) {
                     const uint32_t tile = tile0 + t;
-                    if (tile >= a.tile_end) break;
-                    uint32_t u = __builtin_popcount((hq0 ^ zc0[t]) & zm0[t]) + hnu;
+                    if (SMAFA_ZONE_NLIVE ? t >= nl : tile >= a.tile_end) break;
+                    const uint32_t zc = SMAFA_ZONE_SGPR_ZONE ? zc0[t] : (uint32_t)__builtin_amdgcn_readlane((int)vz.x, (int)t);
+                    const uint32_t zm = SMAFA_ZONE_SGPR_ZONE ? zm0[t] : (uint32_t)__builtin_amdgcn_readlane((int)vz.y, (int)t);
+                    uint32_t u = __builtin_popcount((hq0 ^ zc) & zm) + hnu;
                     if (zone_w1) {
                         const uint32_t zc1 = (uint32_t)__builtin_amdgcn_readlane((int)vz.z, (int)t);
                         const uint32_t zm1 = (uint32_t)__builtin_amdgcn_readlane((int)vz.w, (int)t);
@@ -1044,9 +1064,11 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
                 // dense neighbourhoods: one pass over the chunk per tile, that tile's planes in registers
                 for (uint32_t t = 0; t < (uint32_t)T; t++) {
                     const uint32_t tile = tile0 + t;
-                    if (tile >= a.tile_end) break;
+                    if (SMAFA_ZONE_NLIVE ? t >= n_live : tile >= a.tile_end) break;
                     uint4 s[PS * W];
-                    const uint4 *src = planes + (size_t)tile * (PS * W * 64) + lane;
+                    uint32_t tile_d = tile;  // opaque: the walk's addresses are formed here, not kept (spilled) from the prologue
+                    asm volatile("" : "+s"(tile_d));
+                    const uint4 *src = planes + (size_t)(SMAFA_ZONE_NLIVE ? tile_d : tile) * (PS * W * 64) + lane;
 #pragma unroll
                     for (int i = 0; i < PS * W; i++) s[i] = src[i * 64];
                     const uint4 *rec = &stage[buf][0];

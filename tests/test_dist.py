@@ -52,6 +52,7 @@ def exit_code_of_ranks(r):
     import re
 
     codes = set(int(m) for m in re.findall(r"exitcode\s*:\s*(-?\d+)", r.stderr))
+    codes.discard(-15)  # a rank the launcher terminated after the first one had failed
     return codes.pop() if len(codes) == 1 else (0 if r.returncode == 0 else sorted(codes))
 
 
