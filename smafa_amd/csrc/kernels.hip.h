@@ -65,6 +65,9 @@ __host__ __device__ constexpr int scan_min_waves(int ps, int w, int t) {
 #ifndef SMAFA_SUM_FOLD
 #define SMAFA_SUM_FOLD 1  // scan_kernel<.., FOLD = 1 | 2> for two-word launches with a bound of 13..17 | 18..32 (engine.hip launch_scan_t)
 #endif
+#ifndef SMAFA_SIGN_COMPARE
+#define SMAFA_SIGN_COMPARE 1  // scan_kernel's full comparison: one sign test per query instead of a compare per subject
+#endif
 #ifndef SMAFA_AND_PAIR
 #define SMAFA_AND_PAIR 0  // 1: the folded bound takes two subjects per popcount (popcount(a & b) <= both).  +5 % in round 1 at
                           // bound 5; nothing today at tight bounds (the zone level runs in front), and at bounds 9-13 it
@@ -340,6 +343,52 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
     auto full_compare = [&](const uint32_t(&qw)[RS], uint32_t q) {
         const uint32_t U = ~qw[BS];
         uint32_t lo = 0xffffffffu;  // SEED only
+#if SMAFA_SIGN_COMPARE
+        if (!SEED) {
+            // The distances are accumulated on top of ~bound (v_bcnt's accumulator adds it for free), so "within the bound"
+            // is the sign bit, the 4*T sign bits are OR-ed, and ONE compare + ballot per query replaces a compare and a
+            // branch per subject (the launch with the prefilter off ran 90 scalar instructions per 1024 pairs, most of them
+            // these branches: profiles/r03_pmc.json).  A wave that has a subject in range (rare) looks at them one by one.
+            const uint32_t nuU = qw[BS];
+            uint32_t dd[T][4];
+            uint32_t any = 0;
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+#pragma unroll
+                for (int w = 0; w < W; w++) {
+                    uint32_t extra = 0;
+#pragma unroll
+                    for (int p = PS; p < PQ; p++) extra |= qw[qslot(PQ, W, p, w)];
+                    uint32_t m0 = extra, m1 = extra, m2 = extra, m3 = extra;
+#pragma unroll
+                    for (int p = 0; p < PS; p++) {
+                        const uint4 v = s[t][p * W + w];
+                        const uint32_t qv = qw[qslot(PQ, W, p, w)];
+                        const bool first = p == 0 && PS == PQ;
+                        m0 = first ? (v.x ^ qv) : or_xor(m0, v.x, qv);
+                        m1 = first ? (v.y ^ qv) : or_xor(m1, v.y, qv);
+                        m2 = first ? (v.z ^ qv) : or_xor(m2, v.z, qv);
+                        m3 = first ? (v.w ^ qv) : or_xor(m3, v.w, qv);
+                    }
+                    dd[t][0] = (w ? dd[t][0] : nuU) + __builtin_popcount(m0);
+                    dd[t][1] = (w ? dd[t][1] : nuU) + __builtin_popcount(m1);
+                    dd[t][2] = (w ? dd[t][2] : nuU) + __builtin_popcount(m2);
+                    dd[t][3] = (w ? dd[t][3] : nuU) + __builtin_popcount(m3);
+                }
+                any = t ? or3(or3(dd[t][0], dd[t][1], dd[t][2]), dd[t][3], any) : (or3(dd[t][0], dd[t][1], dd[t][2]) | dd[t][3]);
+            }
+            if (__ballot((int32_t)any < 0) == 0ull) return;  // nobody within the bound (a bound of L and more: every pair is)
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                const uint32_t subj0 = (tile0 + t) * kWaveTile + lane * 4u;
+                const bool live = tile0 + t < a.tile_end;  // a trailing tile slot holds a copy of another tile: ignore it
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (live && (int32_t)dd[t][k] < 0 && subj0 + k < a.n_subjects) emit(a, rs, buf, q, subj0 + k, dd[t][k] - nuU);
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int t = 0; t < T; t++) {
             uint32_t d[4];

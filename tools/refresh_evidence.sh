@@ -1,22 +1,69 @@
 #!/bin/bash
 # On the GPU box, after ANY change to kernels.hip.h / engine.hip (the build id changes): collect the counter records of
-# the four workloads bench.py looks up, assemble profiles/r02_pmc.json, take the bench lines of record with it in place,
-# and leave everything under gpurun_out/evidence/ in the names profiles/ uses (copy them over afterwards).
-#   gpurun --timeout 1150 -- 'cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && tools/refresh_evidence.sh'
+# every workload bench.py looks up (tools/collect_pmc.py: rocprofv3 --pmc passes of the same bench command, program directly
+# after `--`), assemble profiles/r03_pmc.json, take the bench line of record with it in place, and leave everything under
+# gpurun_out/evidence/ in the names profiles/ uses (copy them over afterwards).  Two calls (a gpurun call is capped at 20 min):
+#   gpurun --timeout 1150 -- 'cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && tools/refresh_evidence.sh a'
+#   gpurun --timeout 1150 -- 'cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && tools/refresh_evidence.sh b'
+# `b` expects the records of `a` under gpurun_out/ev_*/ (gpurun merges gpurun_out back between calls... on the BUILD side:
+# the records travel inside gpurun_out/evidence/part_a.json, which must be copied to profiles/r03_pmc_part_a.json first).
 cd "$(dirname "$0")/.."
 E=gpurun_out/evidence
 mkdir -p $E
-python3 tools/collect_pmc.py --tag ev_aa > $E/collect_aa.log 2>&1 || exit 1
-python3 tools/collect_pmc.py --tag ev_nt -- --alphabet nt --queries 100000 --max-div 3 > $E/collect_nt.log 2>&1 || exit 1
-python3 tools/collect_pmc.py --tag ev_rel -- --store related > $E/collect_rel.log 2>&1 || exit 1
-python3 tools/collect_pmc.py --tag ev_50m -- --db-rows 50000000 --queries 125000 > $E/collect_50m.log 2>&1 || exit 1
-python3 - <<'PY'
+part=${1:-a}
+light="--skip-stats --passes sq_a,fetch,write"
+collect() {  # tag, collect_pmc flags..., -- bench flags
+  local tag=$1; shift
+  python3 tools/collect_pmc.py --tag $tag "$@" > $E/collect_$tag.log 2>&1 || { echo "collect $tag failed"; tail -5 $E/collect_$tag.log; return 1; }
+  echo "collected $tag ($(date +%T))"
+}
+if [ "$part" = a ]; then
+  collect ev_aa || exit 1
+  collect ev_unf $light --steps 5 -- --prefilter 0 || exit 1
+  collect ev_d8 $light -- --max-div 8 || exit 1
+  collect ev_d14 $light -- --max-div 14 || exit 1
+  collect ev_d24 $light -- --max-div 24 || exit 1
+  collect ev_best $light --steps 4 -- --mode besthit || exit 1
+  python3 - <<'PY'
+import json
+tags = ("ev_aa", "ev_unf", "ev_d8", "ev_d14", "ev_d24", "ev_best")
+json.dump({"records": [json.load(open("gpurun_out/%s/pmc_record.json" % t)) for t in tags]}, open("gpurun_out/evidence/part_a.json", "w"), indent=1)
+PY
+else
+  collect ev_rel $light -- --store related || exit 1
+  collect ev_1m $light -- --db-rows 1000000 || exit 1
+  collect ev_nt $light -- --alphabet nt --queries 100000 --max-div 3 || exit 1
+  collect ev_ntn $light -- --alphabet nt --queries 100000 --max-div 3 --n-frac 0.001 || exit 1
+  collect ev_50m $light --steps 4 -- --db-rows 50000000 --queries 125000 || exit 1
+  python3 tools/collect_pmc.py --tag ev_cluster --cluster > $E/collect_ev_cluster.log 2>&1 || { echo "collect cluster failed"; exit 1; }
+  echo "collected cluster ($(date +%T))"
+  python3 - <<'PY'
 import csv, glob, json, os, shutil
 E = "gpurun_out/evidence"
-recs = [json.load(open("gpurun_out/%s/pmc_record.json" % t)) for t in ("ev_aa", "ev_nt", "ev_50m", "ev_rel")]
-json.dump({"records": recs}, open(E + "/r02_pmc.json", "w"), indent=1)
-shutil.copy(E + "/r02_pmc.json", "profiles/r02_pmc.json")  # on the box: the bench lines below look it up
-kernel = recs[0]["kernel"].replace("smafa::", "")
+recs = json.load(open("profiles/r03_pmc_part_a.json"))["records"] if os.path.exists("profiles/r03_pmc_part_a.json") else []
+recs += [json.load(open("gpurun_out/%s/pmc_record.json" % t)) for t in ("ev_rel", "ev_1m", "ev_nt", "ev_ntn", "ev_50m", "ev_cluster")]
+json.dump({"records": recs}, open(E + "/r03_pmc.json", "w"), indent=1)
+shutil.copy(E + "/r03_pmc.json", "profiles/r03_pmc.json")  # on the box: the bench line below looks it up
+PY
+  python3 bench.py --steps 20 --warmup 5 > $E/r03_bench.json 2> $E/bench.err || exit 1
+  python3 - <<'PY'
+import json
+d = json.load(open("gpurun_out/evidence/r03_bench.json"))
+r = d["roofline"]
+print("headline %.3f ms/step %.3f M q/s frac %s this build %s verified %s run %s s" % (d["ms_per_step"], d["value"] / 1e6, r.get("frac"), r.get("insts_source_is_this_build"), d["verified"], d["run_s"]))
+for k in ("unfiltered", "besthit_unbounded", "related"):
+    if d.get(k): print(k, d[k].get("kernel_ms"), d[k]["roofline"].get("frac"))
+for x in d.get("loose_bounds") or []: print("bound", x["max_divergence"], x["kernel_ms"], x["roofline"].get("frac"))
+for k, v in (d.get("configs") or {}).items(): print(k, v.get("kernel_ms"), (v.get("roofline") or {}).get("frac"), v.get("verified"))
+print("stream", d["stream"]["roofline"])
+PY
+fi
+if [ "$part" = a ]; then
+  python3 - <<'PY'
+import csv, glob, json, os, shutil
+E = "gpurun_out/evidence"
+rec = json.load(open("gpurun_out/ev_aa/pmc_record.json"))
+kernel = rec["kernel"].replace("smafa::", "")
 def only_scan(src_glob, dst):
     rows, head = [], None
     for path in glob.glob(src_glob, recursive=True):
@@ -28,19 +75,10 @@ def only_scan(src_glob, dst):
     if head:
         with open(dst, "w", newline="") as f:
             w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC); w.writerow(head); w.writerows(rows)
-for stats in glob.glob("gpurun_out/ev_aa/stats/**/*kernel_stats.csv", recursive=True): shutil.copy(stats, E + "/r02_kernel_stats.csv")
-only_scan("gpurun_out/ev_aa/stats/**/*kernel_trace.csv", E + "/r02_kernel_trace_scan.csv")
+for stats in glob.glob("gpurun_out/ev_aa/stats/**/*kernel_stats.csv", recursive=True): shutil.copy(stats, E + "/r03_kernel_stats.csv")
+only_scan("gpurun_out/ev_aa/stats/**/*kernel_trace.csv", E + "/r03_kernel_trace_scan.csv")
 for p in ("sq_a", "sq_b", "fetch", "write"):
-    only_scan("gpurun_out/ev_aa/%s/**/*counter_collection.csv" % p, E + "/r02_pmc_%s_scan_rows.csv" % p)
+    only_scan("gpurun_out/ev_aa/%s/**/*counter_collection.csv" % p, E + "/r03_pmc_%s_scan_rows.csv" % p)
 PY
-python3 bench.py --steps 20 > $E/r02_bench.json 2> $E/bench.err || exit 1
-python3 bench.py --steps 20 --alphabet nt --queries 100000 --max-div 3 --no-related --no-cpu-baseline > $E/r02_bench_nt_10M_100k_d3.json 2>> $E/bench.err || exit 1
-python3 bench.py --steps 20 --alphabet nt --queries 100000 --max-div 3 --n-frac 0.001 --no-related --no-cpu-baseline > $E/r02_bench_nt_10M_100k_d3_withN.json 2>> $E/bench.err || exit 1
-python3 bench.py --steps 50 --db-rows 1000000 --no-related --no-cpu-baseline > $E/r02_bench_aa_1M_10k_d5.json 2>> $E/bench.err || exit 1
-python3 bench.py --steps 5 --warmup 2 --db-rows 50000000 --queries 125000 --no-related --no-cpu-baseline > $E/r02_bench_aa_50M_125k_d5.json 2>> $E/bench.err || exit 1
-python3 - <<'PY'
-import json
-for n in ("r02_bench", "r02_bench_nt_10M_100k_d3", "r02_bench_nt_10M_100k_d3_withN", "r02_bench_aa_1M_10k_d5", "r02_bench_aa_50M_125k_d5"):
-    d = json.load(open("gpurun_out/evidence/%s.json" % n)); r = d["roofline"]
-    print("%-34s %.3f ms/step  %.3f M q/s  frac %s  this build: %s  verified %s  %s" % (n, d["ms_per_step"], d["value"] / 1e6, r.get("frac"), r.get("insts_source_is_this_build"), d.get("verified"), r["kernel"]))
-PY
+fi
+echo "part $part done"
