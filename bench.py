@@ -1101,7 +1101,7 @@ def cluster_config(np, synth, args, build_id):
         for r_ in pmc_records():
             if r_.get("config", {}).get("mode") == "cluster":
                 rec = r_
-        if rec and stages.get("scan_kernels_ms"):
+        if rec and rec.get("per_launch", {}).get("SQ_INSTS_VALU") and stages.get("scan_kernels_ms"):
             lane_ops = float(rec["per_launch"]["SQ_INSTS_VALU"]) * 64.0 / (stages["scan_kernels_ms"] * 1e-3)
             out["roofline"] = {"bound": "valu", "kernel": "all scan kernels of the run", "achieved": lane_ops / 1e12,
                                "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "Tlane-op/s", "frac": lane_ops / VALU_PEAK_LANE_OPS,

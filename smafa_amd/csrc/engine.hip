@@ -126,6 +126,7 @@ struct smafa_db {
     bool sort_rows = true;        // sort big appends by their filter words (SMAFA_SORT=0: keep the append order)
     smafa_qset scratch_q;     // query set of smafa_scan_hits / smafa_distances
     smafa_qset scratch_q2;    // the compacted batch of queries the near-hit probe did not finish
+    smafa_qset scratch_q3;    // the sample of open queries the later steps of the ladder are planned from
     bool two_phase = true;    // near-hit probe before the tightening path (SMAFA_TWO_PHASE=0 disables)
     uint32_t count_first_k = 3;  // smallest k whose loose-bound scans count first and append second (SMAFA_COUNT_FIRST_K)
     // rows of a smafa_scan_hits call that ended in SMAFA_ERR_CAPACITY, kept for the caller's "grow and retry":
@@ -1024,9 +1025,75 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
         done.swap(all);
     };
     const bool laddered = k_mode >= 1 && db->use_filter && db->lazy && db->two_phase && n_queries >= 16;
+    // Which LATER steps pay is estimated once, on a sample of the queries the first step left open: every (cur_n / 512)-th
+    // open query is scanned in the k-th mode at the ladder's last bound, and the distribution of their k-th distances says
+    // what share of the open queries each later step would finish.  A step costs about 0.3 (bounds the OR-fold still
+    // rejects at) or 0.5 (the per-word sums of two planes) of what the loose path costs per query (10M x 60 aa, 10 000
+    // queries: 8.4 / 15 / 30 ms, profiles/r03_bench.json); the cheapest sequence of steps + loose path for the rest wins.
+    // (Round 2 stopped after any step that finished less than an eighth: queries 9-14 columns away from their nearest
+    // subject — novel members of a family — then paid the loose path in full: 33 ms per 10 000 instead of ~17.)
+    std::vector<char> run_step(ladder.size(), 1);
+    bool planned = false;
+    auto plan_later_steps = [&](size_t from) -> int {
+        planned = true;
+        size_t last = from;
+        while (last + 1 < ladder.size() && ladder[last + 1] < limit) last++;
+        if (from >= ladder.size() || ladder[from] >= limit) return SMAFA_OK;
+        const uint32_t ns = std::min<uint32_t>(512u, cur_n / 4u);
+        const uint32_t stride = cur_n / ns;
+        std::vector<uint8_t> sample((size_t)ns * db->L);
+        for (uint32_t i = 0; i < ns; i++) memcpy(&sample[(size_t)i * db->L], cur + (size_t)i * stride * db->L, db->L);
+        int prc = qset_fill(&db->scratch_q3, db, sample.data(), ns);
+        if (prc) return prc;
+        unsigned long long count = 0;
+        prc = scan_range(db, &db->scratch_q3, 0, ns, ladder[last], k_mode, db->hits.as<smafa_hit>(), db->hits_cap(),
+                         db->count.as<unsigned long long>());
+        if (prc) return prc;
+        HIP_TRY(hipMemcpyAsync(&count, db->count.p, sizeof count, hipMemcpyDeviceToHost, db->stream));
+        HIP_TRY(hipStreamSynchronize(db->stream));
+        note_call_scan(db);
+        std::vector<uint32_t> kth(ns, UINT32_MAX);  // k-th smallest distance of each sample query within the last bound
+        if (count > db->hits_cap()) {
+            std::fill(kth.begin(), kth.end(), 0u);  // too dense to look at: every step will finish plenty
+        } else if (count) {
+            std::vector<smafa_hit> rows;
+            prc = fetch_rows(db, count, 0, ns, rows);
+            if (prc) return prc;
+            for (size_t i = 0; i < rows.size();) {
+                size_t j = i;
+                while (j < rows.size() && rows[j].query == rows[i].query) j++;
+                if (j - i >= k_mode) kth[rows[i].query] = rows[i + k_mode - 1].dist;
+                i = j;
+            }
+        }
+        const size_t n_later = last - from + 1;  // at most two steps today: every subset is tried
+        double best_cost = 1.0;                   // no further step: the loose path for everybody
+        uint32_t best_mask = 0;
+        for (uint32_t mask = 1; mask < (1u << n_later); mask++) {
+            double cost = 0.0, open_share = 1.0;
+            for (size_t t = 0; t < n_later; t++) {
+                if (!((mask >> t) & 1u)) continue;
+                const uint32_t b = ladder[from + t];
+                size_t fin = 0;
+                for (uint32_t v : kth) fin += v <= b;
+                cost += open_share * (b <= 3u * cols / 8u ? 0.3 : 0.5);
+                open_share = 1.0 - (double)fin / (double)ns;
+            }
+            cost += open_share;
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_mask = mask;
+            }
+        }
+        for (size_t t = from; t < ladder.size(); t++) run_step[t] = t <= last && ((best_mask >> (t - from)) & 1u);
+        log_line(2, "near-hit plan from a sample of %u open queries: steps at%s%s -> %.2f of the loose path's cost", ns,
+                 n_later >= 1 && (best_mask & 1u) ? " first" : "", n_later >= 2 && (best_mask & 2u) ? " second" : "", best_cost);
+        return SMAFA_OK;
+    };
     for (size_t step = 0; laddered && step < ladder.size() && cur_n >= 16; step++) {
         const uint32_t bound = ladder[step];
         if (limit <= bound || (step > 0 && bound <= ladder[step - 1])) break;
+        if (!run_step[step]) continue;
         unsigned long long count = 0;
         // the step itself runs in the tightening mode (bound lowered to each query's k-th distance as the scan
         // proceeds), so on dense stores only the rows within the final bound come back, not every pair within it
@@ -1036,7 +1103,15 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
         HIP_TRY(hipMemcpyAsync(&count, db->count.p, sizeof count, hipMemcpyDeviceToHost, db->stream));
         HIP_TRY(hipStreamSynchronize(db->stream));
         note_call_scan(db);
-        if (count == 0 || count > db->hits_cap()) break;  // nobody near / too dense to look at: the full path decides
+        if (count > db->hits_cap()) break;  // too dense to look at: the full path decides
+        if (count == 0) {  // nobody within this bound: do the later steps pay?
+            if (!planned && cur_n >= 2048 && step + 1 < ladder.size()) {
+                rc = plan_later_steps(step + 1);
+                if (rc) return rc;
+                continue;
+            }
+            break;
+        }
         std::vector<smafa_hit> near;
         rc = fetch_rows(db, count, 0, cur_n, near);
         if (rc) return rc;
@@ -1045,7 +1120,14 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
         std::vector<uint32_t> open;  // positions in the current batch that still need an answer, ascending
         for (uint32_t q = 0; q < cur_n; q++)
             if (have[q] < k_mode) open.push_back(q);
-        if (open.size() == cur_n) break;
+        if (open.size() == cur_n) {
+            if (!planned && cur_n >= 2048 && step + 1 < ladder.size()) {
+                rc = plan_later_steps(step + 1);
+                if (rc) return rc;
+                continue;
+            }
+            break;
+        }
         std::vector<smafa_hit> fin;
         fin.reserve(near.size());
         for (smafa_hit h : near)
@@ -1071,7 +1153,12 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
         rc = qset_fill(&db->scratch_q2, db, cur, cur_n);
         if (rc) return rc;
         qs = &db->scratch_q2;
-        if (!paid) break;
+        if (!planned && cur_n >= 2048 && step + 1 < ladder.size()) {
+            rc = plan_later_steps(step + 1);  // (the sample is drawn from the compacted batch of open queries)
+            if (rc) return rc;
+        } else if (!planned && !paid) {
+            break;  // a small batch: round 2's rule of thumb
+        }
     }
     if (cur_n > 0) {
         std::vector<smafa_hit> far;
@@ -1318,7 +1405,8 @@ void smafa_db_destroy(smafa_db *db) {
     if (db->d_zone) (void)hipFree(db->d_zone);
     for (DevBuf *b : {&db->upload, &db->hits, &db->count, &db->scratch, &db->ctrs, &db->keys_a, &db->keys_b, &db->sort_tmp,
                       &db->idx_a, &db->idx_b, &db->d_perm, &db->d_tab, &db->scratch_q.qrec,
-                      &db->scratch_q.thr, &db->scratch_q.cnt, &db->scratch_q2.qrec, &db->scratch_q2.thr, &db->scratch_q2.cnt})
+                      &db->scratch_q.thr, &db->scratch_q.cnt, &db->scratch_q2.qrec, &db->scratch_q2.thr, &db->scratch_q2.cnt,
+                      &db->scratch_q3.qrec, &db->scratch_q3.thr, &db->scratch_q3.cnt})
         b->release();
     if (db->each_graph) (void)hipGraphExecDestroy(db->each_graph);
     if (db->ev0) (void)hipEventDestroy(db->ev0);

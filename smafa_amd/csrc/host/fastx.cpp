@@ -21,6 +21,10 @@
 
 namespace smafa {
 
+// host/inflate_other.cpp
+int inflate_bzip2(const char *path, const uint8_t *in, size_t n, std::vector<uint8_t> &out);
+int inflate_xz(const char *path, const uint8_t *in, size_t n, std::vector<uint8_t> &out);
+
 int FastxReader::open(const char *path) {
     path_ = path;
     FILE *f = fopen(path, "rb");
@@ -28,17 +32,27 @@ int FastxReader::open(const char *path) {
     unsigned char magic[6] = {0};
     const size_t got = fread(magic, 1, sizeof magic, f);
     fclose(f);
-    if (got >= 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h')
-        return set_error(SMAFA_ERR_INVALID, "%s: bzip2 input is not supported by this build", path);  // (not a reference panic: exit 1)
-    if (got >= 6 && magic[0] == 0xfd && magic[1] == '7' && magic[2] == 'z' && magic[3] == 'X' && magic[4] == 'Z')
-        return set_error(SMAFA_ERR_INVALID, "%s: xz input is not supported by this build", path);
+    const bool bz2 = got >= 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h';
+    const bool xz = got >= 6 && magic[0] == 0xfd && magic[1] == '7' && magic[2] == 'z' && magic[3] == 'X' && magic[4] == 'Z';
     data_.clear();
     if (map_) munmap(map_, size_);
     map_ = nullptr;
     base_ = nullptr;
     size_ = 0;
     const bool gz = got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b;
-    if (!gz) {  // plain file: mapped when it is a regular file, otherwise read to the end
+    if (bz2 || xz) {  // needletail sniffs these two as well (Cargo.toml:27): the file image is mapped and decompressed whole
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return set_error(SMAFA_ERR_IO, "%s: cannot open", path);
+        struct stat st;
+        void *m = MAP_FAILED;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) return set_error(SMAFA_ERR_IO, "%s: cannot map", path);
+        const int rc = bz2 ? inflate_bzip2(path, (const uint8_t *)m, (size_t)st.st_size, data_)
+                           : inflate_xz(path, (const uint8_t *)m, (size_t)st.st_size, data_);
+        munmap(m, (size_t)st.st_size);
+        if (rc) return rc;
+    } else if (!gz) {  // plain file: mapped when it is a regular file, otherwise read to the end
         const int fd = ::open(path, O_RDONLY);
         if (fd < 0) return set_error(SMAFA_ERR_IO, "%s: cannot open", path);
         struct stat st;

@@ -491,3 +491,44 @@ def test_query_file_parts_partition_the_records(tmp_path, kind):
     with gzip.open(gz, "wb") as g:
         g.write(b"".join(recs))
     assert smafa_amd.load_fastx_part(gz, 0, 2)[2] is False
+
+
+@pytest.mark.parametrize("kind", ["bz2", "bz2_two_streams", "xz", "xz_two_streams"])
+def test_bzip2_and_xz_inputs(tmp_path, kind):
+    """needletail reads bzip2 and xz input as well as gzip (Cargo.toml:27; call sites src/lib.rs:144,221,381): makedb, count and
+    the loaders give the bytes of the uncompressed file; a truncated stream is an error, not a short read"""
+    import bz2
+    import lzma
+
+    rng = np.random.default_rng(8)
+    n, L = 5000, 60
+    s = rng.integers(0, 5, size=(n, L), dtype=np.uint8)
+    from smafa_amd import synth
+    plain = str(tmp_path / "s.fna")
+    synth.write_fasta(plain, s, 0)
+    raw = open(plain, "rb").read()
+    half = raw.index(b">", len(raw) // 2)
+    if kind == "bz2":
+        blob = bz2.compress(raw)
+    elif kind == "bz2_two_streams":
+        blob = bz2.compress(raw[:half]) + bz2.compress(raw[half:])
+    elif kind == "xz":
+        blob = lzma.compress(raw, format=lzma.FORMAT_XZ)
+    else:
+        blob = lzma.compress(raw[:half], format=lzma.FORMAT_XZ) + lzma.compress(raw[half:], format=lzma.FORMAT_XZ)
+    packed = str(tmp_path / ("s.fna." + kind.split("_")[0]))
+    open(packed, "wb").write(blob)
+    assert smafa_amd.load_fastx(packed).tobytes() == s.tobytes()
+    db_a, db_b = str(tmp_path / "a.db"), str(tmp_path / "b.db")
+    assert cli("makedb", "-i", plain, "-d", db_a).returncode == 0
+    r = cli("makedb", "-i", packed, "-d", db_b)
+    assert r.returncode == 0, r.stderr
+    assert open(db_a, "rb").read() == open(db_b, "rb").read()
+    want = oracle.run_cli("count", "-i", plain).stdout.replace(plain, packed)
+    assert cli("count", "-i", packed).stdout == want
+    rows, err, usable = smafa_amd.load_fastx_part(packed, 0, 2)
+    assert usable is False  # a compressed stream cannot be taken in byte ranges
+    open(packed, "wb").write(blob[: len(blob) - 40])
+    r = cli("makedb", "-i", packed, "-d", db_b)
+    assert r.returncode == 101 and ("truncated" in r.stderr or "damaged" in r.stderr), r.stderr  # .expect(..): src/lib.rs:144
+    assert cli("count", "-i", packed).returncode == 1  # `?`: src/lib.rs:381

@@ -271,5 +271,10 @@ def test_bench_self_launch_two_ranks_one_gpu_gloo():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["verified"] is True and out["steps"] == 2
-    frac = out["roofline"]["frac"]  # claimed only where profiles/r02_pmc.json holds counters of this workload and kernel
+    frac = out["roofline"]["frac"]  # claimed only where profiles/ holds counters of this workload and kernel
     assert out["roofline"]["bound"] == "valu" and (frac is None or 0 < frac <= 1.0)
+    # what crosses a link per rank and step is [count | the rows found (+ headroom)], not the capacity buffer:
+    # 16 bytes of header + 12 bytes per row
+    rows = out["checks"]["gathered_rows_total"] / 2
+    assert out["checks"]["rows_fit_gathered_width"] is True
+    assert 16 + 12 * rows <= out["gathered_bytes_per_rank_per_step"] <= 16 + 12 * (2.0 * rows + 128), out["gathered_bytes_per_rank_per_step"]

@@ -738,3 +738,37 @@ def test_big_fastq_and_gzip_query_files_take_the_threaded_loader(tmp_path):
         assert got.returncode == want.returncode == 101, path
         assert got.stdout == want.stdout
         assert got.stderr.strip().splitlines()[-1] == want.stderr.strip().splitlines()[-1]
+
+
+@pytest.mark.parametrize("alphabet,n_letters", [(0, 4), (1, 20)])
+def test_near_hit_ladder_planned_from_a_sample(alphabet, n_letters):
+    """the k-th-distance modes without a tight bound on a BIG query batch: after the first bounded step the later steps are
+    chosen from a sample of the open queries (engine.hip plan_later_steps) — near, middling (8..20 columns away) and
+    unrelated queries mixed, each mix compared with the oracle's exhaustive answer"""
+    rng = np.random.default_rng(77 + alphabet)
+    n, L, nq = 30_000, 60, 6_000
+    s = rng.integers(0, n_letters, size=(n, L), dtype=np.uint8)
+    s[500:520] = s[499]
+
+    def planted(count, lo, hi):
+        q = s[rng.integers(0, n, size=count)].copy()
+        for r in q:
+            for c in rng.choice(L, size=int(rng.integers(lo, hi + 1)), replace=False):
+                r[c] = (r[c] + 1 + rng.integers(0, n_letters - 1)) % n_letters
+        return q
+
+    near, mid = planted(nq // 3, 0, 4), planted(nq // 3, 8, 20)
+    far = rng.integers(0, n_letters, size=(nq - len(near) - len(mid), L), dtype=np.uint8)
+    mixes = {"all kinds": np.concatenate([near, mid, far]), "middling only": np.concatenate([mid, mid[::-1]]),
+             "unrelated only": np.concatenate([far, far[::-1]]), "near first, then unrelated": np.concatenate([near, far, far])}
+    store = smafa_amd.SubjectStore(L, alphabet)
+    store.push(s)
+    for name, q in mixes.items():
+        perm = rng.permutation(len(q))
+        q = q[perm]
+        full = oracle.scan_codes(s, q, L)
+        for D, k in ((None, 1), (None, 3), (40, 1), (25, 2)):
+            got = store.scan(q, max_divergence=D, max_num_hits=k)
+            want = expected_with_k(full if D is None else full[full["dist"] <= D], k)
+            assert got.tobytes() == want.tobytes(), (name, D, k, len(got), len(want))
+    store.close()

@@ -10,11 +10,13 @@ OUT=${OUT:-/tmp/asan}
 mkdir -p "$OUT"
 make -C "$ROOT/smafa_amd/csrc" -j8 >/dev/null
 cd "$ROOT/smafa_amd/csrc"
-for f in common alphabet fastx dbfile select packed layout drivers; do
+for f in common group qsession inflate_other alphabet fastx dbfile select packed layout drivers; do
   g++ -O1 -g -std=c++17 -fPIC -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -c host/$f.cpp -o "$OUT/$f.o"
 done
 g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined -c host/main.cpp -o "$OUT/main.o"
-g++ -fsanitize=address,undefined -pthread -o "$OUT/smafa_asan" "$OUT"/*.o ../build/engine.o -L/opt/rocm/lib -lamdhip64 -lz -lpthread -Wl,-rpath,/opt/rocm/lib
+g++ -fsanitize=address,undefined -pthread -o "$OUT/smafa_asan" "$OUT"/*.o ../build/engine.o -L/opt/rocm/lib -lamdhip64 -lz -lpthread -ldl -Wl,-rpath,/opt/rocm/lib
+g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined -c "$ROOT/tools/asan_parts.cpp" -o "$OUT/parts_main.oo"
+g++ -fsanitize=address,undefined -pthread -o "$OUT/parts_asan" "$OUT/parts_main.oo" $(ls "$OUT"/*.o | grep -v main.o) ../build/engine.o -L/opt/rocm/lib -lamdhip64 -lz -lpthread -ldl -Wl,-rpath,/opt/rocm/lib
 cd "$ROOT"
 export ASAN_OPTIONS=detect_leaks=0
 python3 - "$OUT" <<'PY'
@@ -64,6 +66,16 @@ open(out + "/big.fq", "wb").write(fq); open(out + "/big.fq.gz", "wb").write(gzip
 open(out + "/cut.fq", "wb").write(fq[: len(fq) - 37]); open(out + "/cut.fq.gz", "wb").write(gzip.compress(fq, 1)[:-4000])
 for f in ("big.fq", "big.fq.gz", "cut.fq", "cut.fq.gz"):
     run("makedb", "-i", out + "/" + f, "-d", out + "/fq.db"); run("count", "-i", out + "/" + f)
+# bzip2 / xz input (decoded by the system's libbz2 / liblzma through dlopen): whole, truncated and mutated streams
+import bz2, lzma
+for name, blob in (("s.bz2", bz2.compress(fa_small := open(out + "/small.fna", "rb").read())), ("s.xz", lzma.compress(fa_small))):
+    open(out + "/" + name, "wb").write(blob)
+    run("makedb", "-i", out + "/" + name, "-d", out + "/c.db"); run("count", "-i", out + "/" + name)
+    for i in range(40):
+        d = bytearray(blob)
+        for _ in range(rng.randint(1, 3)): d[rng.randrange(4, len(d))] = rng.randrange(256)
+        open(out + "/m_" + name, "wb").write(bytes(d[: rng.randrange(6, len(d))] if i % 2 else d))
+        run("makedb", "-i", out + "/m_" + name, "-d", out + "/c.db"); run("count", "-i", out + "/m_" + name)
 # a packed store header over garbage: the loader must refuse it before anything is indexed
 import struct
 hdr = b"\x03\x02SMAFA\x00" + struct.pack("<4I11Q", 0, 60, 2, 2, 1000, 4, 1, 4096, 8192, 12288, 16384, 20480, 24576, 28672, 28672 + 4 * 2 * 2 * 256 * 4)
@@ -87,6 +99,20 @@ for i in range(200):
     open(out + "/m.fna", "wb").write(bytes(d[: rng.randrange(1, len(d))] if i % 3 == 0 else d))
     run("makedb", "-i", out + "/m.fna", "-d", out + "/m2.db"); run("count", "-i", out + "/m.fna")
     run("cluster", "-i", out + "/m.fna", "-d", "2"); run("query", "-d", out + "/small.db", "-q", out + "/m.fna")
+# the per-part loader of the one-process-per-GPU query path (smafa_fastx_load_part): every part of whole, truncated and mutated
+# FASTA / FASTQ files, for several part counts; usable parts must add up to the whole file's records
+P = os.path.join(out, "parts_asan")
+part_files = [out + "/small.fna", out + "/big.fq", out + "/cut.fq", out + "/big.fq.gz", out + "/big.fna"]
+for i in range(60):
+    d = bytearray(fa)
+    for _ in range(rng.randint(1, 4)): d[rng.randrange(len(d))] = rng.choice(b">\n\r@+ACGTNx-\x00\xff")
+    path = out + "/pm%d.fna" % i
+    open(path, "wb").write(bytes(d[: rng.randrange(1, len(d))] if i % 3 == 0 else d))
+    part_files.append(path)
+r = subprocess.run([P, *part_files], capture_output=True)
+if b"AddressSanitizer" in r.stderr or b"runtime error" in r.stderr or r.returncode != 0:
+    findings += 1
+    print("FINDING parts", r.returncode, r.stdout[-600:].decode(errors="replace"), r.stderr[:800].decode(errors="replace"))
 print("sanitizer findings:", findings)
 sys.exit(1 if findings else 0)
 PY

@@ -226,8 +226,9 @@ def cluster_main(a, out, prof):
     for name, counters in (("sq_a", SQ_A), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
         d = os.path.join(out, "cluster_" + name)
         with open(os.path.join(out, "cluster_" + name + ".log"), "w") as f:
+            # (the CLI normally leaves through _exit, which would skip the profiler's own exit handler)
             rc = subprocess.run([prof, "--pmc", *counters, "--kernel-trace", "-d", d, "-o", name, "--output-format", "csv", "--", *cli],
-                                stdout=subprocess.DEVNULL, stderr=f, cwd=ROOT).returncode
+                                stdout=subprocess.DEVNULL, stderr=f, cwd=ROOT, env=dict(os.environ, SMAFA_NO_FAST_EXIT="1")).returncode
         print("cluster", name, "pass rc", rc, flush=True)
         tot, nd, ms, bk = per_call(counter_rows(d), 1)
         merged.update(tot)

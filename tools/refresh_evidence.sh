@@ -2,11 +2,9 @@
 # On the GPU box, after ANY change to kernels.hip.h / engine.hip (the build id changes): collect the counter records of
 # every workload bench.py looks up (tools/collect_pmc.py: rocprofv3 --pmc passes of the same bench command, program directly
 # after `--`), assemble profiles/r03_pmc.json, take the bench line of record with it in place, and leave everything under
-# gpurun_out/evidence/ in the names profiles/ uses (copy them over afterwards).  Two calls (a gpurun call is capped at 20 min):
-#   gpurun --timeout 1150 -- 'cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && tools/refresh_evidence.sh a'
-#   gpurun --timeout 1150 -- 'cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && tools/refresh_evidence.sh b'
-# `b` expects the records of `a` under gpurun_out/ev_*/ (gpurun merges gpurun_out back between calls... on the BUILD side:
-# the records travel inside gpurun_out/evidence/part_a.json, which must be copied to profiles/r03_pmc_part_a.json first).
+# gpurun_out/evidence/ in the names profiles/ uses (copy them over afterwards).  Three parts, in one call (about six minutes)
+# or in several (then copy gpurun_out/evidence/part_<x>.json to profiles/r03_pmc_part_<x>.json in between):
+#   gpurun --timeout 1150 -- 'cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && tools/refresh_evidence.sh a && tools/refresh_evidence.sh b && tools/refresh_evidence.sh c'
 cd "$(dirname "$0")/.."
 E=gpurun_out/evidence
 mkdir -p $E
@@ -29,19 +27,30 @@ import json
 tags = ("ev_aa", "ev_unf", "ev_d8", "ev_d14", "ev_d24", "ev_best")
 json.dump({"records": [json.load(open("gpurun_out/%s/pmc_record.json" % t)) for t in tags]}, open("gpurun_out/evidence/part_a.json", "w"), indent=1)
 PY
-else
+elif [ "$part" = b ]; then
   collect ev_rel $light -- --store related || exit 1
   collect ev_1m $light -- --db-rows 1000000 || exit 1
   collect ev_nt $light -- --alphabet nt --queries 100000 --max-div 3 || exit 1
   collect ev_ntn $light -- --alphabet nt --queries 100000 --max-div 3 --n-frac 0.001 || exit 1
   collect ev_50m $light --steps 4 -- --db-rows 50000000 --queries 125000 || exit 1
+  python3 - <<'PY'
+import json
+tags = ("ev_rel", "ev_1m", "ev_nt", "ev_ntn", "ev_50m")
+json.dump({"records": [json.load(open("gpurun_out/%s/pmc_record.json" % t)) for t in tags]}, open("gpurun_out/evidence/part_b.json", "w"), indent=1)
+PY
+else  # part c: the cluster record, the assembled file, the bench line of record
   python3 tools/collect_pmc.py --tag ev_cluster --cluster > $E/collect_ev_cluster.log 2>&1 || { echo "collect cluster failed"; exit 1; }
   echo "collected cluster ($(date +%T))"
   python3 - <<'PY'
 import csv, glob, json, os, shutil
 E = "gpurun_out/evidence"
-recs = json.load(open("profiles/r03_pmc_part_a.json"))["records"] if os.path.exists("profiles/r03_pmc_part_a.json") else []
-recs += [json.load(open("gpurun_out/%s/pmc_record.json" % t)) for t in ("ev_rel", "ev_1m", "ev_nt", "ev_ntn", "ev_50m", "ev_cluster")]
+recs = []
+for part in ("a", "b"):  # the parts travel as profiles/r03_pmc_part_<x>.json (copied there from gpurun_out/evidence/ between calls)
+    for path in ("gpurun_out/evidence/part_%s.json" % part, "profiles/r03_pmc_part_%s.json" % part):
+        if os.path.exists(path):
+            recs += json.load(open(path))["records"]
+            break
+recs.append(json.load(open("gpurun_out/ev_cluster/pmc_record.json")))
 json.dump({"records": recs}, open(E + "/r03_pmc.json", "w"), indent=1)
 shutil.copy(E + "/r03_pmc.json", "profiles/r03_pmc.json")  # on the box: the bench line below looks it up
 PY
