@@ -148,7 +148,7 @@ def test_native_sharded_query_parts_packed_store_gzip_and_bad_records(tmp_path, 
     st.push(codes)
     st.save(packed)
     st.close()
-    for f in (flags, [], ["--max-num-hits", "4", "--limit-per-sequence", "1"]):
+    for f in (flags, [], ["--max-num-hits", "4", "--limit-per-sequence", "1"])[: 3 if world == 2 else 1]:
         w = oracle.run_cli("query", "-d", db, "-q", qf, *f)
         r = run_world(world, packed, qf, out, f, hip=True)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -162,7 +162,7 @@ def test_native_sharded_query_parts_packed_store_gzip_and_bad_records(tmp_path, 
     assert open(out).read() == want.stdout
     # a bad byte in the first share / in the last share
     raw = open(qf, "rb").read().split(b">")
-    for victim in (20, 200):
+    for victim in (20, 200) if world == 2 else (200,):
         bad = list(raw)
         bad[victim + 1] = bad[victim + 1][:-5] + b"E" + bad[victim + 1][-4:]
         bf = str(tmp_path / ("bad%d.fna" % victim))
@@ -178,6 +178,8 @@ def test_native_sharded_query_parts_packed_store_gzip_and_bad_records(tmp_path, 
     open(one, "wb").write(b">" + raw[1])
     r = run_world(world, packed, one, out, ["--limit-per-sequence", "1"], hip=True)
     assert exit_code_of_ranks(r) == 101 and r.stderr.count("limit_per_sequence is implemented unless max_num_hits > 1") >= world, r.stderr[-3000:]
+    if world > 2:  # (every launch of torch.distributed.run costs ~2 s: the remaining cases run with two ranks only)
+        return
     # a missing query file is a panic (exit 101), a missing DB an Err (exit 1) — on every rank
     r = run_world(world, packed, str(tmp_path / "nope.fna"), out, flags, hip=True)
     assert exit_code_of_ranks(r) == 101, r.stderr[-1000:]
