@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "engine.h"
@@ -1006,6 +1007,9 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
     if (db->W == 2 && db->L >= 33) {  // two words: scan_kernel's FOLD 1 / FOLD 2 forms still reject at 13..17 / 18..32
         // (a step at 16 in front of the one at 30 costs nearly as much and is redundant: queries 0..30 substitutions away
         // from their subject, 10 000 x 10M aa: 35 ms with both, profiles/r02_besthit_ladder.txt)
+        // (three planes and more: a step at 17, the top of FOLD 1's range — 12 ms where the step at 30 costs 15 — is there for
+        // the planner below to choose when most open queries lie within it)
+        if (db->P >= 3) ladder.push_back(17u);
         ladder.push_back(db->P >= 3 ? 30u : 16u);
     }
     const uint32_t limit = std::min<uint32_t>(max_div, db->L);
@@ -1028,8 +1032,9 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
     // Which LATER steps pay is estimated once, on a sample of the queries the first step left open: every (cur_n / 256)-th
     // open query is scanned in the k-th mode at the ladder's last bound, and the distribution of their k-th distances says
     // what share of the open queries each later step would finish.  A step costs about 0.3 (bounds the OR-fold still
-    // rejects at) or 0.5 (the per-word sums of two planes) of what the loose path costs per query (10M x 60 aa, 10 000
-    // queries: 8.4 / 15 / 30 ms, profiles/r03_bench.json); the cheapest sequence of steps + loose path for the rest wins.
+    // rejects at), 0.4 (FOLD 1: the filter plane's per-word sums) or 0.5 (FOLD 2: two planes) of what the loose path costs
+    // per query (10M x 60 aa, 10 000 queries: 8.4 / 12 / 15 / 29 ms, profiles/r03_bench.json); the cheapest sequence of
+    // steps + loose path for the rest wins.
     // (Round 2 stopped after any step that finished less than an eighth: queries 9-14 columns away from their nearest
     // subject — novel members of a family — then paid the loose path in full: 33 ms per 10 000 instead of ~17.)
     std::vector<char> run_step(ladder.size(), 1);
@@ -1076,7 +1081,7 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
                 const uint32_t b = ladder[from + t];
                 size_t fin = 0;
                 for (uint32_t v : kth) fin += v <= b;
-                cost += open_share * (b <= 3u * cols / 8u ? 0.3 : 0.5);
+                cost += open_share * (b <= 3u * cols / 8u ? 0.3 : b <= 17u ? 0.4 : 0.5);
                 open_share = 1.0 - (double)fin / (double)ns;
             }
             cost += open_share;
@@ -1086,8 +1091,11 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
             }
         }
         for (size_t t = from; t < ladder.size(); t++) run_step[t] = t <= last && ((best_mask >> (t - from)) & 1u);
-        log_line(2, "near-hit plan from a sample of %u open queries: steps at%s%s -> %.2f of the loose path's cost", ns,
-                 n_later >= 1 && (best_mask & 1u) ? " first" : "", n_later >= 2 && (best_mask & 2u) ? " second" : "", best_cost);
+        std::string chosen;
+        for (size_t t = 0; t < n_later; t++)
+            if ((best_mask >> t) & 1u) chosen += " " + std::to_string(ladder[from + t]);
+        log_line(2, "near-hit plan from a sample of %u open queries: further steps at bounds [%s ] -> %.2f of the loose path's cost",
+                 ns, chosen.c_str(), best_cost);
         return SMAFA_OK;
     };
     for (size_t step = 0; laddered && step < ladder.size() && cur_n >= 16; step++) {
