@@ -129,6 +129,7 @@ struct smafa_db {
     smafa_qset scratch_q2;    // the compacted batch of queries the near-hit probe did not finish
     smafa_qset scratch_q3;    // the sample of open queries the later steps of the ladder are planned from
     bool two_phase = true;    // near-hit probe before the tightening path (SMAFA_TWO_PHASE=0 disables)
+    bool fold3 = true;        // scan_kernel's all-planes-but-the-last bound for launches whose bound starts above 32 (SMAFA_FOLD3=0)
     uint32_t count_first_k = 3;  // smallest k whose loose-bound scans count first and append second (SMAFA_COUNT_FIRST_K)
     // rows of a smafa_scan_hits call that ended in SMAFA_ERR_CAPACITY, kept for the caller's "grow and retry":
     // the retry with the same arguments against the same store is answered without scanning again
@@ -463,6 +464,8 @@ static void launch_scan_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
     if (SMAFA_SUM_FOLD && W == 2 && !seed && a.use_filter) {
         if (a.thr0 > 12u && a.thr0 <= 17u) fold = 1;
         else if (PS >= 3 && a.thr0 >= 18u && a.thr0 <= 32u) fold = 2;
+        else if (PS >= 4 && a.thr0 > 32u && db->fold3) fold = 3;  // all planes but the last (the k-th modes without a bound)
+        else if (PS == 3 && a.thr0 > 32u && db->fold3) fold = 2;  // three planes: "all but the last" IS the two-plane form
     }
     note_kernel(db, "smafa::scan_kernel<%d, %d, %d, %d, %s, %d>", PS, PQ, W, T, seed ? "true" : "false", fold);
     const uint4 *planes = reinterpret_cast<const uint4 *>(db->d_planes);
@@ -472,6 +475,8 @@ static void launch_scan_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
         hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, false, (W == 2 ? 1 : 0)>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
     else if (W == 2 && PS >= 3 && fold == 2)
         hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, false, (W == 2 && PS >= 3 ? 2 : 0)>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
+    else if (W == 2 && PS >= 4 && fold == 3)
+        hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, false, (W == 2 && PS >= 4 ? 3 : 0)>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
     else
         hipLaunchKernelGGL((scan_kernel<PS, PQ, W, T, false, 0>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
 }
@@ -1289,6 +1294,7 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     }
     if (const char *lv = getenv("SMAFA_LAZY")) db->lazy = atoi(lv) != 0;
     if (const char *pv2 = getenv("SMAFA_TWO_PHASE")) db->two_phase = atoi(pv2) != 0;
+    if (const char *f3 = getenv("SMAFA_FOLD3")) db->fold3 = atoi(f3) != 0;
     if (const char *cv = getenv("SMAFA_COUNT_FIRST_K")) db->count_first_k = (uint32_t)std::max(2, atoi(cv));
     if (const char *ov = getenv("SMAFA_WIDE_ONE")) db->wide_one = atoi(ov) != 0;
     if (const char *wv = getenv("SMAFA_WIDE_FROM")) db->wide_from = (uint32_t)std::max(3, atoi(wv));

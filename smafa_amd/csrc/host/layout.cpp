@@ -69,9 +69,17 @@ void compute_layout(int alphabet, uint32_t L, const uint8_t *codes, uint64_t n, 
             }
             score[c] = balance();
         }
-        uint32_t next[2] = {0, 1};  // even codes for side 0, odd for side 1, in code order
+        // even codes for side 0, odd for side 1.  Amino acids: within a side the most frequent letters get the lowest
+        // codes, so the HIGHEST plane is set only for the rarest letters (20 letters: four of them) — the bound that leaves
+        // the last plane out (scan_kernel FOLD 3) then misses a mismatch only between those and the four commonest.
+        // Nucleotides: in code order (A C G T among 0..3).
+        uint32_t next[2] = {0, 1};
         bool used[32] = {false};
-        for (uint32_t v = 0; v < n_sym; v++) {
+        uint32_t order_v[32];
+        for (uint32_t v = 0; v < n_sym; v++) order_v[v] = v;
+        if (aa) std::stable_sort(order_v, order_v + n_sym, [&](uint32_t x, uint32_t y) { return cc[x] > cc[y]; });
+        for (uint32_t k = 0; k < n_sym; k++) {
+            const uint32_t v = order_v[k];
             tc[v] = (uint8_t)next[side_of[v]];
             used[next[side_of[v]]] = true;
             next[side_of[v]] += 2;

@@ -63,7 +63,7 @@ __host__ __device__ constexpr int scan_min_waves(int ps, int w, int t) {
                                // 7.1 ms vs 8.6 ms per subject — profiles/r02_short_check.txt)
 #endif
 #ifndef SMAFA_SUM_FOLD
-#define SMAFA_SUM_FOLD 1  // scan_kernel<.., FOLD = 1 | 2> for two-word launches with a bound of 13..17 | 18..32 (engine.hip launch_scan_t)
+#define SMAFA_SUM_FOLD 1  // scan_kernel<.., FOLD = 1 | 2 | 3> for two-word launches with a bound of 13..17 | 18..32 | above (engine.hip launch_scan_t)
 #endif
 #ifndef SMAFA_SIGN_COMPARE
 #define SMAFA_SIGN_COMPARE 1  // scan_kernel's full comparison: one sign test per query instead of a compare per subject
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
                 for (uint32_t i = 0; i < nqc; i++, rec += RV) {
                     uint32_t qw[RS];
                     // fast path: filter-plane words + bound slot only (FOLD 2: the next plane's words as well)
-                    constexpr int HV2 = FOLD == 2 ? (qslot(PQ, W, filter_plane(PQ) == 0 ? 1 : 0, W - 1) + 4) / 4 : HV;
+                    constexpr int HV2 = FOLD == 3 ? RV : FOLD == 2 ? (qslot(PQ, W, filter_plane(PQ) == 0 ? 1 : 0, W - 1) + 4) / 4 : HV;
                     read_record(rec, qw, 0, HV2 > HV ? HV2 : HV);
                     const uint32_t nu = qw[BS];
                     uint32_t any = 0;
@@ -521,6 +521,34 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
                                     t1 += __builtin_popcount(or_xor(s[t][FP * W + w].y ^ qa, s[t][FP2 * W + w].y, qb));
                                     t2 += __builtin_popcount(or_xor(s[t][FP * W + w].z ^ qa, s[t][FP2 * W + w].z, qb));
                                     t3 += __builtin_popcount(or_xor(s[t][FP * W + w].w ^ qa, s[t][FP2 * W + w].w, qb));
+                                }
+                                any = t ? or3(or3(t0, t1, t2), t3, any) : (or3(t0, t1, t2) | t3);
+                            } else if (FOLD == 3) {
+                                // FOLD 3 (launches whose bound starts above 32 — the k-th modes without a bound — on stores
+                                // of 4 planes and more): the distance over ALL PLANES BUT THE LAST.  Two different letters
+                                // share their first PS - 1 code bits only when they are one of the few pairs the last plane
+                                // tells apart (20 letters in 5 bits: 4 such pairs of 190), so this bound sits ~1 below the
+                                // distance and still rejects where the running bound of a query without any relative in the
+                                // store settles (~47 of 60 columns) — for 2 * (PS - 1) bit-ops per subject instead of 2 * PS.
+                                // While bounds are still loose it passes for everybody and the wave falls back to the plain
+                                // comparison (filter_on), as with every other level.
+                                uint32_t t0 = nu, t1 = nu, t2 = nu, t3 = nu;
+#pragma unroll
+                                for (int w = 0; w < W; w++) {
+                                    uint32_t m0 = s[t][w].x ^ qw[qslot(PQ, W, 0, w)], m1 = s[t][w].y ^ qw[qslot(PQ, W, 0, w)];
+                                    uint32_t m2 = s[t][w].z ^ qw[qslot(PQ, W, 0, w)], m3 = s[t][w].w ^ qw[qslot(PQ, W, 0, w)];
+#pragma unroll
+                                    for (int p = 1; p < PS - 1; p++) {
+                                        const uint32_t qv = qw[qslot(PQ, W, p, w)];
+                                        m0 = or_xor(m0, s[t][p * W + w].x, qv);
+                                        m1 = or_xor(m1, s[t][p * W + w].y, qv);
+                                        m2 = or_xor(m2, s[t][p * W + w].z, qv);
+                                        m3 = or_xor(m3, s[t][p * W + w].w, qv);
+                                    }
+                                    t0 += __builtin_popcount(m0);
+                                    t1 += __builtin_popcount(m1);
+                                    t2 += __builtin_popcount(m2);
+                                    t3 += __builtin_popcount(m3);
                                 }
                                 any = t ? or3(or3(t0, t1, t2), t3, any) : (or3(t0, t1, t2) | t3);
                             } else if (FOLD == 1) {
