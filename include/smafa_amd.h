@@ -304,6 +304,11 @@ typedef int (*smafa_allgather_fn)(void *ctx, const void *send, uint64_t send_byt
                                   uint64_t *recv_bytes);
 int smafa_cluster_sharded(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet,
                           uint32_t rank, uint32_t world, smafa_allgather_fn allgather, void *ctx);
+/* The same clustering over several GPUs of one node by ONE process (no torch, no collective library): one host thread per entry
+ * of `devices` (entries may repeat) plays a rank of smafa_cluster_sharded — its own replica of the centroid store, its slice of
+ * every batch — the input is parsed and de-duplicated once for all of them, and the two exchanges per batch go through memory.
+ * Output bytes do not depend on ndev (src/cluster.rs:13-94 semantics). */
+int smafa_cluster_multi(const char *input_fasta, uint32_t max_divergence, int out_fd, const int *devices, int ndev, int alphabet);
 /* count(paths) — src/lib.rs:378-398 (JSON to out_fd).  Host only. */
 int smafa_count(const char *const *paths, uint64_t n_paths, int out_fd);
 

@@ -32,7 +32,7 @@ EXPORTS = [
     "smafa_group_create", "smafa_group_load", "smafa_group_append", "smafa_group_scan_hits", "smafa_group_size",
     "smafa_group_member", "smafa_group_destroy",
     "smafa_qsession_open", "smafa_qsession_info", "smafa_qsession_scan_part", "smafa_qsession_write", "smafa_qsession_close",
-    "smafa_makedb", "smafa_makedb_packed", "smafa_query", "smafa_query_multi", "smafa_cluster", "smafa_cluster_sharded", "smafa_count",
+    "smafa_makedb", "smafa_makedb_packed", "smafa_query", "smafa_query_multi", "smafa_cluster", "smafa_cluster_multi", "smafa_cluster_sharded", "smafa_count",
 ]
 
 
@@ -139,6 +139,7 @@ def lib() -> C.CDLL:
     l.smafa_query.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
     l.smafa_query_multi.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.c_int]
     l.smafa_cluster.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_int]
+    l.smafa_cluster_multi.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
     l.smafa_cluster_sharded.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                                         ALLGATHER_FN, vp]
     l.smafa_count.argtypes = [C.POINTER(C.c_char_p), C.c_uint64, C.c_int]

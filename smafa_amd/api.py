@@ -381,8 +381,13 @@ def query(db_path: str, query_fasta: str, max_divergence: Optional[int] = None, 
 
 
 def cluster(input_fasta: str, max_divergence: int, out_fd: int = 1, device: int = 0,
-            alphabet: int = ALPHABET_NT) -> None:
-    """cluster(input_fasta, max_divergence, print_stream) — src/cluster.rs:13-94."""
+            alphabet: int = ALPHABET_NT, devices=None) -> None:
+    """cluster(input_fasta, max_divergence, print_stream) — src/cluster.rs:13-94.
+    `devices`: a list of GPU ordinals (entries may repeat) = one process, one host thread and centroid replica per entry."""
+    if devices is not None:
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        check(lib().smafa_cluster_multi(os.fsencode(input_fasta), int(max_divergence), out_fd, arr, len(devices), alphabet))
+        return
     check(lib().smafa_cluster(os.fsencode(input_fasta), int(max_divergence), out_fd, device, alphabet))
 
 

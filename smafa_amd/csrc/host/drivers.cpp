@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -586,55 +588,67 @@ int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_diver
 // Sharded over `world` processes (one GPU each, smafa_cluster_sharded): steps 1 and 2 scan only this rank's
 // contiguous slice of the batch, the slices' results are exchanged through the caller's allgather, and step 3
 // runs identically on every rank, so the replicas of the centroid store stay equal without a broadcast.
-static int cluster_run(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet,
-                       uint32_t rank, uint32_t world, smafa_allgather_fn allgather, void *ctx) {
+// the input of a clustering run, parsed and de-duplicated ONCE (every rank of a sharded run works from the same records)
+struct ClusterInput {
+    BulkRecords recs;
+    std::vector<uint32_t> uniq;  // first occurrences, input order (src/cluster.rs:46-48)
+    int pending = SMAFA_OK;      // the record that stopped the load fails AFTER the lines of the records before it are written
+    std::string pending_msg;
+    double t_start = 0;
+};
+
+static int cluster_load(const char *input_fasta, int alphabet, int device, ClusterInput &in) {
     if (!input_fasta) return set_error(SMAFA_ERR_INVALID, "smafa_cluster: NULL path");
-    if (world == 0 || rank >= world) return set_error(SMAFA_ERR_INVALID, "rank %u outside world of %u", rank, world);
-    if (world > 1 && !allgather) return set_error(SMAFA_ERR_INVALID, "smafa_cluster_sharded: NULL allgather");
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
-    const double t_start = now_seconds();
-    int rc = SMAFA_OK;
+    in.t_start = now_seconds();
     log_line(1, "Clustering ..");  // src/cluster.rs:33
-
     std::thread warm(warm_device, device);  // device bring-up overlaps the parse
-    BulkRecords recs;
-    rc = load_records_bulk(input_fasta, alphabet, true, recs);  // src/cluster.rs:28,35-43 for every record
+    BulkRecords &recs = in.recs;
+    int rc = load_records_bulk(input_fasta, alphabet, true, recs);  // src/cluster.rs:28,35-43 for every record
     warm.join();
     if (rc) return expect_fastx(rc, "valid path/file of input fasta");  // src/cluster.rs:28
-    std::vector<uint8_t> &raw = recs.raw, &codes = recs.codes;
-    const uint64_t n = recs.n;
-    const size_t L = recs.L;
-    if (n >= 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many records");
-    // the record that stopped the load fails AFTER the lines of the records before it have been written
-    int pending = SMAFA_OK;
-    std::string pending_msg;
+    if (recs.n >= 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many records");
     if (recs.err_kind == 1) {  // src/lib.rs:38-41
-        pending = SMAFA_ERR_PANIC;
-        pending_msg = recs.err_msg;
+        in.pending = SMAFA_ERR_PANIC;
+        in.pending_msg = recs.err_msg;
     } else if (recs.err_kind == 3) {  // first record becomes a centroid: push_encoding, src/lib.rs:103-108
-        pending = SMAFA_ERR_PANIC;
-        pending_msg = "Cannot add empty sequence to WindowSet";
+        in.pending = SMAFA_ERR_PANIC;
+        in.pending_msg = "Cannot add empty sequence to WindowSet";
     } else if (recs.err_kind == 2) {  // get_distances, src/lib.rs:72-79
         char msg[160];
         snprintf(msg, sizeof msg, "Cannot compute distances between seq of length %zu and windows of lengths %zu",
-                 recs.err_len, L);
-        pending = SMAFA_ERR_PANIC;
-        pending_msg = msg;
+                 recs.err_len, recs.L);
+        in.pending = SMAFA_ERR_PANIC;
+        in.pending_msg = msg;
     } else if (recs.err_kind == 4) {  // record.expect(..), src/cluster.rs:39
-        pending = SMAFA_ERR_PANIC;
-        pending_msg = "Failed to parse input sequence: " + recs.err_msg;
+        in.pending = SMAFA_ERR_PANIC;
+        in.pending_msg = "Failed to parse input sequence: " + recs.err_msg;
     }
-
     const double t_loaded = now_seconds();
+    if (recs.n > 0) {
+        in.uniq.reserve(recs.n);
+        first_occurrences(recs.codes.data(), recs.n, (uint32_t)recs.L, in.uniq);  // src/cluster.rs:46-48
+        log_line(2, "parsed %llu records in %.2f s, %zu distinct found in %.2f s", (unsigned long long)recs.n,
+                 t_loaded - in.t_start, in.uniq.size(), now_seconds() - t_loaded);
+    }
+    return SMAFA_OK;
+}
+
+static int cluster_run(const ClusterInput &in, uint32_t max_divergence, int out_fd, int device, int alphabet,
+                       uint32_t rank, uint32_t world, smafa_allgather_fn allgather, void *ctx) {
+    if (world == 0 || rank >= world) return set_error(SMAFA_ERR_INVALID, "rank %u outside world of %u", rank, world);
+    if (world > 1 && !allgather) return set_error(SMAFA_ERR_INVALID, "smafa_cluster_sharded: NULL allgather");
+    const double t_start = in.t_start;
+    int rc = SMAFA_OK;
+    const std::vector<uint8_t> &raw = in.recs.raw, &codes = in.recs.codes;
+    const std::vector<uint32_t> &uniq = in.uniq;
+    const uint64_t n = in.recs.n;
+    const size_t L = in.recs.L;
+    const int pending = in.pending;
+    const std::string &pending_msg = in.pending_msg;
     if (n > 0) {
         const uint32_t Lw = (uint32_t)L;
-        // exact-duplicate skip (src/cluster.rs:46-48): first occurrences only, input order
-        std::vector<uint32_t> uniq;
-        uniq.reserve(n);
-        first_occurrences(codes.data(), n, Lw, uniq);
-        log_line(2, "parsed %llu records in %.2f s, %zu distinct found in %.2f s", (unsigned long long)n,
-                 t_loaded - t_start, uniq.size(), now_seconds() - t_loaded);
         std::vector<uint32_t> centroid_of(n, UINT32_MAX);  // record -> centroid ordinal
         std::vector<uint32_t> centroid_rec;                // centroid ordinal -> record
 
@@ -831,12 +845,95 @@ static int cluster_run(const char *input_fasta, uint32_t max_divergence, int out
 }
 
 int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet) {
-    return cluster_run(input_fasta, max_divergence, out_fd, device, alphabet, 0, 1, nullptr, nullptr);
+    ClusterInput in;
+    int rc = cluster_load(input_fasta, alphabet, device, in);
+    if (rc) return rc;
+    return cluster_run(in, max_divergence, out_fd, device, alphabet, 0, 1, nullptr, nullptr);
 }
 
 int smafa_cluster_sharded(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet,
                           uint32_t rank, uint32_t world, smafa_allgather_fn allgather, void *ctx) {
-    return cluster_run(input_fasta, max_divergence, out_fd, device, alphabet, rank, world, allgather, ctx);
+    if (world == 0 || rank >= world) return set_error(SMAFA_ERR_INVALID, "rank %u outside world of %u", rank, world);
+    if (world > 1 && !allgather) return set_error(SMAFA_ERR_INVALID, "smafa_cluster_sharded: NULL allgather");
+    ClusterInput in;
+    int rc = cluster_load(input_fasta, alphabet, device, in);
+    if (rc) return rc;
+    return cluster_run(in, max_divergence, out_fd, device, alphabet, rank, world, allgather, ctx);
+}
+
+// ---- the same clustering over several GPUs of one node by ONE process: one host thread per entry of `devices` plays a
+// rank of smafa_cluster_sharded (its own replica of the centroid store on its own device, its slice of every batch), the
+// input is parsed and de-duplicated once for all of them, and the two exchanges per batch go through memory.
+namespace {
+struct ThreadExchange {
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t world = 0, arrived = 0;
+    uint64_t round = 0;
+    bool failed = false;
+    std::vector<std::vector<uint8_t>> parts;
+    std::vector<uint8_t> all[2];  // the result of round r lives in all[r & 1] until round r + 2 overwrites it
+};
+struct ThreadRank {
+    ThreadExchange *ex;
+    uint32_t rank;
+};
+int thread_allgather(void *ctx, const void *send, uint64_t send_bytes, const void **recv, uint64_t *recv_bytes) {
+    ThreadRank *me = (ThreadRank *)ctx;
+    ThreadExchange &ex = *me->ex;
+    std::unique_lock<std::mutex> lock(ex.m);
+    if (ex.failed) return 1;
+    ex.parts[me->rank].assign((const uint8_t *)send, (const uint8_t *)send + send_bytes);
+    const uint64_t my_round = ex.round;
+    if (++ex.arrived == ex.world) {
+        std::vector<uint8_t> &out = ex.all[my_round & 1];
+        out.clear();
+        for (const auto &p : ex.parts) out.insert(out.end(), p.begin(), p.end());
+        ex.arrived = 0;
+        ex.round++;
+        ex.cv.notify_all();
+    } else {
+        ex.cv.wait(lock, [&] { return ex.round != my_round || ex.failed; });
+        if (ex.round == my_round) return 1;  // somebody failed before the round completed
+    }
+    *recv = ex.all[my_round & 1].empty() ? nullptr : ex.all[my_round & 1].data();
+    *recv_bytes = ex.all[my_round & 1].size();
+    return 0;
+}
+}  // namespace
+
+int smafa_cluster_multi(const char *input_fasta, uint32_t max_divergence, int out_fd, const int *devices, int ndev, int alphabet) {
+    if (!devices || ndev < 1 || ndev > 64) return set_error(SMAFA_ERR_INVALID, "smafa_cluster_multi: 1 to 64 devices expected");
+    ClusterInput in;
+    int rc = cluster_load(input_fasta, alphabet, devices[0], in);
+    if (rc) return rc;
+    if (ndev == 1) return cluster_run(in, max_divergence, out_fd, devices[0], alphabet, 0, 1, nullptr, nullptr);
+    ThreadExchange ex;
+    ex.world = (uint32_t)ndev;
+    ex.parts.resize((size_t)ndev);
+    std::vector<int> rcs((size_t)ndev, SMAFA_OK);
+    std::vector<std::string> msgs((size_t)ndev);
+    std::vector<ThreadRank> ranks((size_t)ndev);
+    std::vector<std::thread> pool;
+    for (int r = 0; r < ndev; r++) {
+        ranks[r] = {&ex, (uint32_t)r};
+        pool.emplace_back([&, r] {
+            rcs[r] = cluster_run(in, max_divergence, out_fd, devices[r], alphabet, (uint32_t)r, (uint32_t)ndev, thread_allgather, &ranks[r]);
+            if (rcs[r]) {
+                msgs[r] = smafa_last_error();  // the text is per thread
+                std::lock_guard<std::mutex> lock(ex.m);
+                ex.failed = true;  // nobody waits for a rank that has left
+                ex.cv.notify_all();
+            }
+        });
+    }
+    for (auto &th : pool) th.join();
+    // every rank reports the same input-borne failure; a rank-local one (a device) is the first one's to tell
+    for (int r = 0; r < ndev; r++)
+        if (rcs[r] && msgs[r].find("allgather failed") == std::string::npos) return set_error(rcs[r], "%s", msgs[r].c_str());
+    for (int r = 0; r < ndev; r++)
+        if (rcs[r]) return set_error(rcs[r], "%s", msgs[r].c_str());
+    return SMAFA_OK;
 }
 
 // ---------------------------------------------------------------------------------- write_rows

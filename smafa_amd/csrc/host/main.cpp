@@ -6,8 +6,8 @@
 //   cluster -i/--input FILE  -d/--max-divergence INT
 //   count   -i/--input FILE...
 // plus -v/--verbose and --quiet (logging only; results are the only thing on stdout).
-// Additions of this build: --device N (query, cluster), --gpus N (query: GPUs 0..N-1, one handle and host thread
-// each; the output does not depend on N), --devices a,b,.. (query: explicit list, entries may repeat),
+// Additions of this build: --device N (query, cluster), --gpus N (query, cluster: GPUs 0..N-1, one handle and host thread
+// each; the output does not depend on N), --devices a,b,.. (query, cluster: explicit list, entries may repeat),
 // --alphabet nt|aa (makedb, cluster), --packed (makedb: the packed store file, host/packed.cpp).
 // Exit status: 0 ok, 101 where the reference panics (a Rust panic exits 101), 1 other failures, 2 usage.
 #include <cstdio>
@@ -36,7 +36,7 @@ static int usage(const char *msg) {
             "        [--limit-per-sequence <INT>] [--device <N> | --gpus <N> | --devices <a,b,..>]\n"
             "        Output columns (tab-separated): query number (0-indexed), subject number (0-indexed),\n"
             "        divergence, subject sequence (dashes and degenerate bases shown as N)\n"
-            "cluster -i, --input <FILE>  -d, --max-divergence <INT>  [--alphabet nt|aa] [--device <N>]\n"
+            "cluster -i, --input <FILE>  -d, --max-divergence <INT>  [--alphabet nt|aa] [--device <N> | --gpus <N> | --devices <a,b,..>]\n"
             "count   -i, --input <FILE>...\n");
     return 2;
 }
@@ -148,7 +148,8 @@ int main(int argc, char **argv) {
             fprintf(stderr, "called `Option::unwrap()` on a `None` value\n");
             return 101;
         }
-        rc = smafa_cluster(input, max_div, 1, (int)device, alphabet);
+        if (devices.empty()) devices.push_back((int)device);
+        rc = smafa_cluster_multi(input, max_div, 1, devices.data(), (int)devices.size(), alphabet);
     } else if (cmd == "count") {
         if (count_paths.empty()) return usage("count needs --input");
         rc = smafa_count(count_paths.data(), count_paths.size(), 1);

@@ -254,6 +254,18 @@ def test_cluster_sharded_argument_checks(tmp_path):
     assert b"valid path/file of input fasta" in l.smafa_last_error()
 
 
+def test_cluster_multi_argument_checks(tmp_path):
+    import ctypes as C
+
+    l = _lib.lib()
+    path = os.fsencode(str(tmp_path / "none.fna"))
+    assert l.smafa_cluster_multi(path, 3, 1, None, 2, 0) == -1
+    devs = (C.c_int * 2)(0, 0)
+    assert l.smafa_cluster_multi(path, 3, 1, devs, 0, 0) == -1
+    assert l.smafa_cluster_multi(path, 3, 1, devs, 2, 0) == -6  # the input is looked at first: .expect(..), src/cluster.rs:28
+    assert b"valid path/file of input fasta" in l.smafa_last_error()
+
+
 def test_dbfile_property_any_shape(tmp_path):
     """hypothesis over shapes and letters: makedb bytes == the oracle's makedb bytes, and read -> write is the
     identity on the file (the v2 wire format of src/lib.rs:54-60,161-162 for every window count and varint width)"""

@@ -239,6 +239,36 @@ def test_sharded_cluster_equals_oracle_and_single_rank(tmp_path, world):
     assert open(single).read() == want.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndev", [1, 2, 3])
+def test_cluster_multi_one_process_equals_oracle(tmp_path, ndev):
+    """smafa_cluster_multi / `smafa cluster --devices ..`: one process, one host thread per handle playing a rank of the sharded
+    cluster, exchanges through memory — the bytes of the oracle's cluster for any number of handles (all on GPU 0 here), also
+    with a bad record behind good ones (same stdout, exit 101)"""
+    path = cluster_input(tmp_path)
+    want = oracle.run_cli("cluster", "-i", path, "-d", "4")
+    assert want.returncode == 0 and len(want.stdout) > 0
+    r = subprocess.run([smafa_amd._lib.CLI_PATH, "cluster", "-i", path, "-d", "4", "--devices", ",".join(["0"] * ndev)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert r.stdout == want.stdout
+    out = str(tmp_path / "api.tsv")
+    fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    try:
+        smafa_amd.cluster(path, 4, out_fd=fd, devices=[0] * ndev)
+    finally:
+        os.close(fd)
+    assert open(out).read() == want.stdout
+    raw = open(path, "rb").read().split(b">")
+    raw[3001] = raw[3001][:-5] + b"E" + raw[3001][-4:]
+    bad = str(tmp_path / "bad.fna")
+    open(bad, "wb").write(b">".join(raw))
+    w = oracle.run_cli("cluster", "-i", bad, "-d", "4")
+    r = subprocess.run([smafa_amd._lib.CLI_PATH, "cluster", "-i", bad, "-d", "4", "--devices", ",".join(["0"] * ndev)],
+                       capture_output=True, text=True)
+    assert w.returncode == 101 and r.returncode == 101 and r.stdout == w.stdout and len(w.stdout) > 0
+
+
 # ---- bench.py --gpus N from a plain shell: the process starts its own ranks (VERDICT r01, item 2)
 def _bench(*flags, timeout=600):
     env = dict(os.environ, OMP_NUM_THREADS="1")

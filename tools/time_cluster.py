@@ -26,3 +26,11 @@ for world in [int(w) for w in os.environ.get("SMAFA_WORLDS", "2,4").split(",") i
     dt = time.time() - t
     got = hashlib.sha256(open("/tmp/cluster.w.out", "rb").read()).hexdigest()  # -o: gloo's banner goes to stdout
     print("world=%d rc=%d %.1fs (incl. %d x python+torch start-up) identical=%s %s" % (world, r.returncode, dt, world, got == want, r.stderr[-420:].decode(errors="replace")), flush=True)
+# one process, several handles (smafa_cluster_multi: host threads as ranks, exchanges through memory) — all on GPU 0 here
+for devs in ("0,0", "0,0,0,0"):
+    t = time.time()
+    r = subprocess.run([_lib.CLI_PATH, "cluster", "-i", "/tmp/cluster.faa", "-d", "5", "--alphabet", "aa", "--devices", devs, "-v"],
+                       stdout=open("/tmp/cluster.m.out", "wb"), stderr=subprocess.PIPE)
+    dt = time.time() - t
+    got = hashlib.sha256(open("/tmp/cluster.m.out", "rb").read()).hexdigest()
+    print("--devices %s rc=%d %.2fs identical=%s %s" % (devs, r.returncode, dt, got == want, " | ".join(l.split("smafa] ")[1] for l in r.stderr.decode(errors="replace").splitlines() if "batches" in l or "scan kernels" in l)), flush=True)
