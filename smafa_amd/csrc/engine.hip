@@ -84,7 +84,7 @@ struct smafa_db {
     uint64_t life_launches = 0;
     // smafa_scan_each: the K one-query launches captured once as a HIP graph and replayed
     hipGraphExec_t each_graph = nullptr;
-    struct EachKey { const void *qs, *hits, *counts; uint64_t cap, nq, generation; uint32_t max_div; int zone; bool filter; } each_key{};
+    struct EachKey { const void *qs, *hits, *counts; uint64_t cap, nq, generation; uint32_t max_div, qb; int zone; bool filter; } each_key{};
     uint32_t qb_override = 0;
     bool use_filter = true;  // exact lower-bound prefilter in the scan kernel (SMAFA_FILTER=0 disables)
     uint32_t tiles_override = 0;  // SMAFA_TILES
@@ -1592,7 +1592,10 @@ int smafa_scan_each(smafa_db *db, smafa_qset *qs, uint32_t max_div, void *d_hits
         db->timed = true;
         return SMAFA_OK;
     }
-    const smafa_db::EachKey key{qs, d_hits, d_counts, cap_per_query, qs->nq, db->generation, max_div, db->zone, db->use_filter};
+    smafa_db::EachKey key;
+    memset(&key, 0, sizeof key);  // (padding bytes take part in the comparison below)
+    key.qs = qs, key.hits = d_hits, key.counts = d_counts, key.cap = cap_per_query, key.nq = qs->nq, key.generation = db->generation;
+    key.max_div = max_div, key.qb = db->qb_override, key.zone = db->zone, key.filter = db->use_filter;
     if (!db->each_graph || memcmp(&key, &db->each_key, sizeof key) != 0) {
         if (db->each_graph) (void)hipGraphExecDestroy(db->each_graph);
         db->each_graph = nullptr;
@@ -1611,8 +1614,7 @@ int smafa_scan_each(smafa_db *db, smafa_qset *qs, uint32_t max_div, void *d_hits
             db->each_graph = nullptr;
             return set_error(SMAFA_ERR_DEVICE, "graph instantiation failed: %s", hipGetErrorString(e));
         }
-        memset(&db->each_key, 0, sizeof db->each_key);
-        db->each_key = key;
+        memcpy(&db->each_key, &key, sizeof key);
     }
     db->last_launches = nq;
     HIP_TRY(hipEventRecord(db->ev0, db->stream));

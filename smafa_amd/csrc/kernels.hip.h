@@ -1068,10 +1068,13 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
                 // Tile by tile, unrolled (the rare levels' address math stays inside their branch thanks to the opaque
                 // tile number below; a run-time tile loop cost 4 % on aa and 27 % on nt at bound 3 in per-tile
                 // bookkeeping — profiles/r02_zone_variants.txt).
-#pragma unroll
-                for (uint32_t t = 0; t < (uint32_t)T; t++) {
+                // (Round 3: the body is a function of the compile-time tile slot, called under `if (nl > t)` — as a loop with a
+                // `break` and a `continue` the compiler threaded a state variable through the four bodies: ~10 scalar
+                // instructions of pure control flow between two tiles, which counts where few queries survive a tile —
+                // nucleotides at bound 3: scalar instructions 1.5 per 1024 pairs against 1.7 vector ones.)
+                auto do_tile = [&](auto slot) {
+                    constexpr uint32_t t = decltype(slot)::value;
                     const uint32_t tile = tile0 + t;
-                    if (SMAFA_ZONE_NLIVE ? t >= nl : tile >= a.tile_end) break;
                     const uint32_t zc = SMAFA_ZONE_SGPR_ZONE ? zc0[t] : (uint32_t)__builtin_amdgcn_readlane((int)vz.x, (int)t);
                     const uint32_t zm = SMAFA_ZONE_SGPR_ZONE ? zm0[t] : (uint32_t)__builtin_amdgcn_readlane((int)vz.y, (int)t);
                     uint32_t u = __builtin_popcount((hq0 ^ zc) & zm) + hnu;
@@ -1081,11 +1084,7 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
                         u += __builtin_popcount((hq1 ^ zc1) & zm1);
                     }
                     unsigned long long m = __ballot((int32_t)u < 0);  // queries of the chunk this tile cannot exclude
-                    if (m == 0ull) continue;
-                    uint4 ft = f0[0];
-#pragma unroll
-                    for (int k = 1; k < T; k++)
-                        if (t == (uint32_t)k) ft = f0[k];
+                    const uint4 ft = f0[t];
                     while (m != 0ull) {
                         const int i = __builtin_ctzll(m);
                         asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(i));  // m &= ~(1 << i) in ONE scalar op (m & (m - 1): three)
@@ -1133,7 +1132,16 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
                         passes++;
                         stream_compare(tile_r, qw, qc + (uint32_t)i);
                     }
-                }
+                };
+                static_assert(T <= 8, "tile slots are spelled out below");
+                if (SMAFA_ZONE_NLIVE ? nl > 0u : tile0 + 0u < a.tile_end) do_tile(std::integral_constant<uint32_t, 0>{});
+                if (T > 1 && (SMAFA_ZONE_NLIVE ? nl > 1u : tile0 + 1u < a.tile_end)) do_tile(std::integral_constant<uint32_t, (T > 1 ? 1 : 0)>{});
+                if (T > 2 && (SMAFA_ZONE_NLIVE ? nl > 2u : tile0 + 2u < a.tile_end)) do_tile(std::integral_constant<uint32_t, (T > 2 ? 2 : 0)>{});
+                if (T > 3 && (SMAFA_ZONE_NLIVE ? nl > 3u : tile0 + 3u < a.tile_end)) do_tile(std::integral_constant<uint32_t, (T > 3 ? 3 : 0)>{});
+                if (T > 4 && (SMAFA_ZONE_NLIVE ? nl > 4u : tile0 + 4u < a.tile_end)) do_tile(std::integral_constant<uint32_t, (T > 4 ? 4 : 0)>{});
+                if (T > 5 && (SMAFA_ZONE_NLIVE ? nl > 5u : tile0 + 5u < a.tile_end)) do_tile(std::integral_constant<uint32_t, (T > 5 ? 5 : 0)>{});
+                if (T > 6 && (SMAFA_ZONE_NLIVE ? nl > 6u : tile0 + 6u < a.tile_end)) do_tile(std::integral_constant<uint32_t, (T > 6 ? 6 : 0)>{});
+                if (T > 7 && (SMAFA_ZONE_NLIVE ? nl > 7u : tile0 + 7u < a.tile_end)) do_tile(std::integral_constant<uint32_t, (T > 7 ? 7 : 0)>{});
                 // an exact comparison from L2 costs ~60 VALU per (query, tile) pair, the dense walk below ~25 for EVERY
                 // pair of the chunk (4 tiles x nqc): switch when more than ~2/5 of the pairs got that far
                 filter_on = passes * 5u <= nqc * 8u;
