@@ -162,3 +162,41 @@ def test_query_selection_at_60_columns_against_a_python_restatement(tmp_path):
         r = oracle.run_cli("query", "-d", db, "-q", qf, *flags)
         assert r.returncode == 0, r.stderr
         assert r.stdout == expected(max_div, k, limit), flags
+
+
+def test_cluster_at_60_columns_against_a_python_restatement(tmp_path):
+    """`cluster` at 60 columns against the loop of src/cluster.rs:35-85 written out in Python over big integers: duplicates
+    (after collapsing) skipped silently, distances to the centroids so far, first minimum wins, a new centroid otherwise; column 1
+    is the RAW record (case and IUPAC letters kept), column 2 the collapsed centroid"""
+    rng = np.random.default_rng(31)
+    L, roots, members = 60, 25, 12
+    base = np.frombuffer(b"ACGT", dtype=np.uint8)
+    r = base[rng.integers(0, 4, size=(roots, L))]
+    recs = np.repeat(r, members, axis=0)
+    for row in recs:
+        for _ in range(rng.integers(0, 5)):
+            row[rng.integers(0, L)] = ALPHABET[rng.integers(0, len(ALPHABET))]
+    recs = recs[rng.permutation(len(recs))]
+    recs[40:46] = recs[3]                      # exact duplicates
+    recs[50] = np.frombuffer(recs[3].tobytes().lower(), dtype=np.uint8)  # the same sequence after collapsing: also a duplicate
+    path = str(tmp_path / "c.fna")
+    oracle.write_fasta(path, [x.tobytes() for x in recs])
+    for D in (0, 2, 5, 9):
+        seen, centroids, lines = set(), [], []
+        for x in recs:
+            raw = x.tobytes()
+            key = big_int_of(raw)
+            if key in seen:
+                continue
+            seen.add(key)
+            d = [distance(raw, c) for c in centroids]
+            m = min(d) if d else 2 * D + 2
+            if m <= D:
+                assigned = d.index(m)
+            else:
+                assigned = len(centroids)
+                centroids.append(raw)
+            lines.append(raw.decode() + "\t" + "".join(COLLAPSED[ONE_HOT[b]] for b in centroids[assigned]) + "\n")
+        got = oracle.run_cli("cluster", "-i", path, "-d", str(D))
+        assert got.returncode == 0, got.stderr
+        assert got.stdout == "".join(lines), D
