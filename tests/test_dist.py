@@ -293,6 +293,33 @@ def test_bench_self_launch_spawns_ranks_on_cpu_only_host():
 
 
 @pytest.mark.gpu
+def test_bench_line_contract_on_a_small_workload():
+    """the JSON line the driver reads: the contract's fields, `roofline` and `cpu_baseline` objects, every side leg verified
+    (a small store: the BASELINE configs block only runs on the metric's own workload)"""
+    import json
+
+    r = _bench("--steps", "3", "--warmup", "1", "--db-rows", "300000", "--queries", "2048", "--cpu-seconds", "0.3", "--no-related")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["verified"] is True and out["vs_baseline"] is None
+    assert out["unit"] == "query seqs/s" and out["higher_is_better"] is True and out["dtype"] == "u32" and "workload" in out["config"]
+    assert abs(out["value"] - 2048 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6
+    assert out["roofline"]["bound"] == "valu" and out["roofline"]["kernel"].startswith("smafa::scan_")
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "query seqs/s" and cb["sample"]
+    st = out["stream"]
+    assert st["roofline"]["bound"] == "hbm" and st["metric_store"]["rows_identical"] is True
+    assert 0 < st["metric_store"]["streaming"]["frac_wall_streamed"] < 1.0
+    assert all(x["verified"] for x in out["loose_bounds"]) and out["besthit_unbounded"]["verified"] is True
+    assert out["host_api"]["rows_identical_to_device_launch"] is True and out["unfiltered"]["kernel_ms"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_self_launch_two_ranks_one_gpu_gloo():
     import json
 
