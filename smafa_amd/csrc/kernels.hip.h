@@ -908,6 +908,10 @@ constexpr int kFewTiles = SMAFA_FEW_TILES;  // wave tiles per wave in scan_zone_
 #define SMAFA_ZONE_SGPR_ZONE 1  // 1: word 0's zone words of the wave's tiles live in scalar registers (those of tiles 1.. end up
                                 // in spilled VGPR lanes); 0: they are read out of their VGPR lane where they are used
 #endif
+#ifndef SMAFA_ZONE_VGPR_MASK
+#define SMAFA_ZONE_VGPR_MASK 6  // word 0's zone masks also in vector registers for stores of up to this many vectors per tile
+                                // (nucleotides: -2.3 %; the amino-acid kernel has no register to spare: profiles/r03_zone_variants.txt)
+#endif
 #ifndef SMAFA_ZONE_NLIVE
 #define SMAFA_ZONE_NLIVE 1  // 1: "tile slot t is inside the range" is ONE scalar (the number of live slots) instead of T lane masks
 #endif
@@ -969,6 +973,15 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
     for (int t = 0; t < T; t++) {
         zc0[t] = (uint32_t)__builtin_amdgcn_readlane((int)vz.x, t);
         zm0[t] = (uint32_t)__builtin_amdgcn_readlane((int)vz.y, t);
+    }
+    // the masks also as (wave-uniform) VECTOR registers where there is room: (q ^ c) & m is then ONE v_bitop3 with a single
+    // scalar operand — otherwise the mask is moved to a vector register in front of every use
+    constexpr bool kMaskInVgpr = PS * W <= SMAFA_ZONE_VGPR_MASK;
+    uint32_t zmv[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        zmv[t] = zm0[t];
+        if (kMaskInVgpr) asm volatile("v_mov_b32 %0, %1" : "=v"(zmv[t]) : "s"(zm0[t]));
     }
     const bool zone_w1 = W > 1 && __ballot(vz.w != 0u) != 0ull;
 
@@ -1077,7 +1090,7 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
                     const uint32_t tile = tile0 + t;
                     const uint32_t zc = SMAFA_ZONE_SGPR_ZONE ? zc0[t] : (uint32_t)__builtin_amdgcn_readlane((int)vz.x, (int)t);
                     const uint32_t zm = SMAFA_ZONE_SGPR_ZONE ? zm0[t] : (uint32_t)__builtin_amdgcn_readlane((int)vz.y, (int)t);
-                    uint32_t u = __builtin_popcount((hq0 ^ zc) & zm) + hnu;
+                    uint32_t u = __builtin_popcount((hq0 ^ zc) & (kMaskInVgpr ? zmv[t] : zm)) + hnu;
                     if (zone_w1) {
                         const uint32_t zc1 = (uint32_t)__builtin_amdgcn_readlane((int)vz.z, (int)t);
                         const uint32_t zm1 = (uint32_t)__builtin_amdgcn_readlane((int)vz.w, (int)t);
