@@ -82,19 +82,26 @@ def parse_args(argv=None):
     ap.add_argument("--time-budget", type=float, default=400.0,
                     help="seconds after start beyond which optional legs are skipped (the driver allows 600 s)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (tests use gloo)")
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="with --gpus 1: initialise the process group anyway and run every collective of the N>1 path over a world of one (an RCCL rehearsal on a one-GPU box)")
     ap.add_argument("--collective", choices=["gather", "all_gather"], default="gather",
                     help="how the per-rank row lists reach rank 0 each step (N > 1)")
     ap.add_argument("--single-device", action="store_true", help="testing only: every rank uses GPU 0")
     return ap.parse_args(argv)
 
 
-def self_launch(args) -> int:
-    """--gpus N > 1 from a plain shell: start the N ranks as a child job.  Nothing in this process has touched
-    torch or the GPU, and it never execs: it waits, and passes the child's output and exit code on."""
+def find_free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+def self_launch(args) -> int:
+    """--gpus N > 1 from a plain shell: start the N ranks as a child job.  Nothing in this process has touched
+    torch or the GPU, and it never execs: it waits, and passes the child's output and exit code on."""
+    port = find_free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     env = dict(os.environ)
@@ -361,9 +368,12 @@ def main() -> int:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.rehearse_collectives  # the N>1 code path (collectives, two buffers); a world of one may rehearse it
+    if multi:
         import torch.distributed as dist
 
+        if "MASTER_ADDR" not in os.environ:  # a rehearsal started without torch.distributed.run
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(find_free_port()), RANK="0", WORLD_SIZE="1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -372,7 +382,7 @@ def main() -> int:
     alphabet = smafa_amd.ALPHABET_AA if args.alphabet == "aa" else smafa_amd.ALPHABET_NT
     L, N, Q, D = args.seq_len, args.db_rows, args.queries, args.max_div
     max_subs = 10 if alphabet == smafa_amd.ALPHABET_AA else 6
-    side_legs = rank == 0 and world == 1 and not args.no_stream
+    side_legs = rank == 0 and not multi and not args.no_stream
     build_id = smafa_amd.build_id()
     skipped = []
 
@@ -415,10 +425,10 @@ def main() -> int:
     cap = max(4 * Q, 1 << 16)
     # one buffer per step parity: [count (u64) | pad | rows], so that ONE collective moves count and rows together
     HEAD = 4  # int32 words before the rows (the count lives in the first two)
-    bufs = [torch.zeros(HEAD + cap * 3, dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
+    bufs = [torch.zeros(HEAD + cap * 3, dtype=torch.int32, device=dev) for _ in range(2 if multi else 1)]
     d_hits, d_count = bufs[0][HEAD:], bufs[0][:2].view(torch.int64)
     gathered_bytes = None
-    if world > 1:
+    if multi:
         # The gather of step i runs on its own stream while the scan of step i+1 runs on the main one (two buffers).
         # north_star: "a final RCCL gather over xGMI of the hit lists" — a gather to rank 0.  What crosses a link per step is
         # [count | the rows this rank found], not the whole capacity buffer: the width every rank sends is the largest row
@@ -437,7 +447,7 @@ def main() -> int:
 
     def step(i_timed: int | None) -> None:
         b = it[0] % len(bufs)
-        if world > 1 and it[0] >= 2:
+        if multi and it[0] >= 2:
             stream.wait_event(gather_done[b])  # the gather that read this buffer two steps ago has finished
         if i_timed is not None:
             ev[i_timed][0].record(stream)
@@ -448,7 +458,7 @@ def main() -> int:
             store.scan_launch(qset, D, None, bufs[b].data_ptr() + 4 * HEAD, cap, bufs[b].data_ptr())
         if i_timed is not None:
             ev[i_timed][1].record(stream)
-        if world > 1:  # RCCL gather of the row lists
+        if multi:  # RCCL gather of the row lists
             scan_done[b].record(stream)
             with torch.cuda.stream(comm):
                 comm.wait_event(scan_done[b])
@@ -464,14 +474,14 @@ def main() -> int:
 
     def fence() -> None:
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step(None)
     fence()
-    if world > 1:
+    if multi:
         # size the gathered block from what the warm-up steps found (all ranks agree on ONE width: MAX over ranks)
         seen = max(int(b[:2].view(torch.int64).item()) for b in bufs) if args.warmup else cap
         w = torch.tensor([seen], dtype=torch.int64, device=dev)
@@ -487,7 +497,7 @@ def main() -> int:
         step(i)
     fence()
     elapsed_s = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_s = float(t.item())
@@ -542,7 +552,7 @@ def main() -> int:
         n_rows = int(d_count.item())
         rows = sorted_rows(d_hits[: 3 * min(n_rows, cap)].cpu().numpy().view(np.uint32).reshape(-1, 3))
         checks["rows_fit"] = n_rows <= cap
-        if world > 1:
+        if multi:
             checks["rows_fit_gathered_width"] = n_rows * 3 + HEAD <= width[0]
             if gathered[last] is not None:
                 # what the gather delivered (on the root; on every rank with all_gather): this rank's block must be its own
@@ -576,7 +586,7 @@ def main() -> int:
             checks["oracle_sample_identical"] = oracle_sample(np, subj, my_q, rows, D, pick)
             checks["oracle_sample_queries"] = int(len(pick))
     ok = all(v for k, v in checks.items() if isinstance(v, bool))
-    if world > 1:
+    if multi:
         flag = torch.tensor([1 if ok else 0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
@@ -763,7 +773,7 @@ def main() -> int:
 
     # ---- CPU baselines: the oracle's port of the reference's per-query loop, bounded samples
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         b = cpu_baselines(N, L, D, args.alphabet, subj, my_q, args.cpu_seconds)
         cpu = {
             "value": b["b1"]["value"], "unit": "query seqs/s", "cores": 1, "kind": "port",
@@ -998,7 +1008,7 @@ def main() -> int:
             "skipped_for_time": skipped,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
     return 0
 

@@ -337,3 +337,41 @@ def test_bench_self_launch_two_ranks_one_gpu_gloo():
     rows = out["checks"]["gathered_rows_total"] / 2
     assert out["checks"]["rows_fit_gathered_width"] is True
     assert 16 + 12 * rows <= out["gathered_bytes_per_rank_per_step"] <= 16 + 12 * (2.0 * rows + 128), out["gathered_bytes_per_rank_per_step"]
+
+
+@pytest.mark.gpu
+def test_rccl_rehearsal_world_of_one(tmp_path):
+    """Nothing in this suite can put two ranks on two GPUs, so the RCCL side of the N>1 path is rehearsed over a world of
+    ONE rank on the one GPU: `python -m smafa_amd.dist query|cluster --backend nccl` (device tensors through all_gather /
+    gather / all_reduce of RCCL, no shortcut for a world of one) must print the oracle CLI's bytes, and `bench.py --gpus 1
+    --rehearse-collectives` runs the timed N>1 loop (two buffers, gather on its own stream, widths by all_reduce MAX)
+    through RCCL and verifies what the gather delivered."""
+    import json
+
+    db, qf = make_inputs(tmp_path, n=3000, q=211, L=60)
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(*args):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), "-m", "smafa_amd.dist", *args]
+        return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+
+    out = str(tmp_path / "o.tsv")
+    for flags in (["--max-divergence", "6", "--max-num-hits", "3"], []):
+        want = oracle.run_cli("query", "-d", db, "-q", qf, *flags)
+        r = run("query", "-d", db, "-q", qf, *flags, "--backend", "nccl", "-o", out)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert open(out).read() == want.stdout and want.stdout
+    path = cluster_input(tmp_path)
+    want = oracle.run_cli("cluster", "-i", path, "-d", "4")
+    r = run("cluster", "-i", path, "-d", "4", "--backend", "nccl", "-o", out)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(out).read() == want.stdout and want.stdout
+    for collective in ("gather", "all_gather"):
+        r = _bench("--gpus", "1", "--rehearse-collectives", "--collective", collective, "--steps", "3", "--warmup", "2",
+                   "--db-rows", "200000", "--queries", "512")
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["verified"] is True and line["n_gpus"] == 1 and line["steps"] == 3
+        c = line["checks"]
+        assert c["gather_block_is_own_buffer"] is True and c["rows_fit_gathered_width"] is True and c["gathered_rows_total"] == line["rows_per_step"]
