@@ -26,8 +26,9 @@ SWITCHES = {"SMAFA_FILTER": ["1", "1", "1", "0"], "SMAFA_LAZY": ["1", "1", "0"],
             "SMAFA_NT_PLANES": ["", "", "3"], "SMAFA_WIDE_FROM": ["5", "5", "3"], "SMAFA_WIDE_ONE": ["1", "1", "0"],
             "SMAFA_TWO_PHASE": ["1", "1", "0"], "SMAFA_COUNT_FIRST_K": ["3", "3", "2", "1000000"],
             "SMAFA_ZONE": ["1", "1", "2", "2", "0"], "SMAFA_SORT": ["1", "1", "0"], "SMAFA_LAYOUT": ["1", "1", "0"],
-            "SMAFA_RESORT": ["1", "1", "1", "0"], "SMAFA_RESORT_MIN": ["", "2", "300", "5000"]}
+            "SMAFA_RESORT": ["1", "1", "1", "0"], "SMAFA_RESORT_MIN": ["", "2", "300", "5000"], "SMAFA_FOLD3": ["1", "1", "0"]}
 print("soak seed", seed0, flush=True)
+t_note = time.time()
 while time.time() < t_end:
     rng = np.random.default_rng(seed0 + rounds)
     rounds += 1
@@ -36,6 +37,8 @@ while time.time() < t_end:
     L = int(rng.choice([1, 2, 7, 12, 20, 31, 32, 33, 60, 60, 60, 64, 65, 90, 96, 128, 129, 150, 200, 257]))
     n = int(rng.choice([1, 3, 255, 256, 257, 1000, 4097, 9000, 20000]))
     nq = int(rng.choice([1, 2, 17, 64, 65, 300]))
+    if n <= 4097 and rng.random() < 0.12:
+        nq = int(rng.choice([2100, 2600]))  # enough open queries for the near-hit ladder to be planned from a sample
     env = {k: str(rng.choice(v)) for k, v in SWITCHES.items()}
     for k, v in env.items():
         if v: os.environ[k] = v
@@ -57,7 +60,8 @@ while time.time() < t_end:
             r[rng.integers(0, L)] = rng.integers(0, n_letters)
     if nq > 3:
         q[0] = rng.integers(0, n_letters, size=L, dtype=np.uint8)
-    store = smafa_amd.SubjectStore(L, alphabet)
+    handles = int(rng.choice([0, 0, 0, 0, 2, 3]))  # >0: the same store behind a group of handles (all on GPU 0)
+    store = smafa_amd.SubjectGroup(L, alphabet, devices=[0] * handles) if handles else smafa_amd.SubjectStore(L, alphabet)
     cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=int(rng.integers(0, 3)))]))
     for a, b in zip(cuts[:-1], cuts[1:]):
         store.push(s[a:b])
@@ -79,8 +83,11 @@ while time.time() < t_end:
         want = full if k is None else expected_with_k(full, k)
         scans += 1
         if got.tobytes() != want.tobytes():
-            print("MISMATCH round", rounds - 1, "seed", seed0, dict(alphabet=alphabet, n_letters=n_letters, L=L, n=n, nq=nq, mode=mode, D=D, k=k,
-                  env=env, got=len(got), want=len(want), plan=store.last_scan_plan()), flush=True)
+            print("MISMATCH round", rounds - 1, "seed", seed0, dict(alphabet=alphabet, n_letters=n_letters, L=L, n=n, nq=nq, mode=mode, D=D, k=k, handles=handles,
+                  env=env, got=len(got), want=len(want), plan=None if handles else store.last_scan_plan()), flush=True)
             sys.exit(1)
     store.close()
+    if time.time() - t_note > 60:  # a line a minute: a silent run is taken for a hung one on the GPU box
+        t_note = time.time()
+        print("  %d stores, %d scans so far" % (rounds, scans), flush=True)
 print("soak ok: %d stores, %d scans in %.0f s" % (rounds, scans, budget), flush=True)
