@@ -34,6 +34,7 @@ extern "C" {
 #define SMAFA_ERR_IO (-4)       /* file could not be read / written */
 #define SMAFA_ERR_FORMAT (-5)   /* malformed FASTX / DB file, unsupported DB version */
 #define SMAFA_ERR_PANIC (-6)    /* input on which the reference panics (message preserved) */
+#define SMAFA_ERR_NOMEM (-7)    /* host memory (or threads) ran out inside the call; the handle it was given may only be destroyed */
 
 #define SMAFA_ALPHABET_NT 0 /* A C G T/U N — classes of BYTE_LUT, src/lib.rs:171-178; codes 0..4 */
 #define SMAFA_ALPHABET_AA 1 /* build-defined extension: A-Z * - (case-folded), codes 0..27; not in the reference */

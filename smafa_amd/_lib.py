@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SMAFA_AMD_LIB") or os.path.join(_HERE, "lib", "libsma
 CLI_PATH = os.path.join(_HERE, "bin", "smafa")
 
 OK = 0
-ERR_INVALID, ERR_DEVICE, ERR_CAPACITY, ERR_IO, ERR_FORMAT, ERR_PANIC = -1, -2, -3, -4, -5, -6
+ERR_INVALID, ERR_DEVICE, ERR_CAPACITY, ERR_IO, ERR_FORMAT, ERR_PANIC, ERR_NOMEM = -1, -2, -3, -4, -5, -6, -7
 NONE = 0xFFFFFFFF
 ALPHABET_NT, ALPHABET_AA = 0, 1
 

@@ -13,6 +13,11 @@ namespace smafa {
 
 // records the message for smafa_last_error() and returns `code`
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+// Inside `catch (...)` of an exported function (every int-returning entry point is a function-try-block: no C++ exception
+// leaves the C ABI): std::bad_alloc / std::length_error / std::system_error -> SMAFA_ERR_NOMEM, anything else ->
+// SMAFA_ERR_INVALID, the message recorded.  (Worker threads do not catch: running out of memory there ends the process,
+// as an allocation failure does in the reference — Rust aborts.)
+int exception_code(const char *where) noexcept;
 
 // Scan `n_queries` code rows against the store; rows ordered by (query, dist, subject); rows above the
 // k-th smallest distance of their query already removed.  max_num_hits: SMAFA_NONE = no k bound.

@@ -1258,13 +1258,15 @@ int db_load_packed(smafa_db **out, int device, const PackedStore &pk) {
 // ------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
-int smafa_device_count(void) {
+int smafa_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+} catch (...) {
+    return smafa::exception_code("smafa_device_count");
 }
 
-int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) {
+int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) try {
     if (!out) return set_error(SMAFA_ERR_INVALID, "smafa_db_create: out is NULL");
     *out = nullptr;
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
@@ -1318,9 +1320,11 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     db->stream = db->own_stream;
     *out = db;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_db_create");
 }
 
-int smafa_db_append(smafa_db *db, const uint8_t *codes, uint64_t n) {
+int smafa_db_append(smafa_db *db, const uint8_t *codes, uint64_t n) try {
     if (!db || (!codes && n)) return set_error(SMAFA_ERR_INVALID, "smafa_db_append: NULL argument");
     if (n == 0) return SMAFA_OK;
     if (db->n + n > 0xffffff00ull) return set_error(SMAFA_ERR_INVALID, "subject store limited to 2^32 rows");
@@ -1347,9 +1351,11 @@ int smafa_db_append(smafa_db *db, const uint8_t *codes, uint64_t n) {
         for (DevBuf *b : {&db->upload, &db->keys_a, &db->keys_b, &db->idx_a, &db->idx_b, &db->sort_tmp}) b->release();
     }
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_db_append");
 }
 
-int smafa_db_save(smafa_db *db, const char *path) {
+int smafa_db_save(smafa_db *db, const char *path) try {
     if (!db || !path) return set_error(SMAFA_ERR_INVALID, "smafa_db_save: NULL argument");
     int rc = use_device(db);
     if (rc) return rc;
@@ -1381,18 +1387,22 @@ int smafa_db_save(smafa_db *db, const char *path) {
         runs.push_back(r.sorted ? 1u : 0u);
     }
     return write_packed_file(path, h, db->perm.data(), db->tab.data(), runs.data(), order.data(), zone.data(), planes.data());
+} catch (...) {
+    return smafa::exception_code("smafa_db_save");
 }
 
-int smafa_db_load(smafa_db **out, int device, const char *path) {
+int smafa_db_load(smafa_db **out, int device, const char *path) try {
     if (!out || !path) return set_error(SMAFA_ERR_INVALID, "smafa_db_load: NULL argument");
     *out = nullptr;
     PackedStore pk;
     int rc = pk.open(path);
     if (rc) return rc;
     return db_load_packed(out, device, pk);
+} catch (...) {
+    return smafa::exception_code("smafa_db_load");
 }
 
-int smafa_db_info(const smafa_db *db, smafa_db_info_t *info) {
+int smafa_db_info(const smafa_db *db, smafa_db_info_t *info) try {
     if (!db || !info) return set_error(SMAFA_ERR_INVALID, "smafa_db_info: NULL argument");
     info->n_subjects = db->n;
     info->seq_len = db->L;
@@ -1403,12 +1413,16 @@ int smafa_db_info(const smafa_db *db, smafa_db_info_t *info) {
     info->bytes_per_subject = (uint64_t)db->P * db->W * 4;
     info->hbm_bytes = (db->n + kWaveTile - 1) / kWaveTile * db->tile_words() * sizeof(uint32_t);
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_db_info");
 }
 
-int smafa_db_set_stream(smafa_db *db, void *hip_stream) {
+int smafa_db_set_stream(smafa_db *db, void *hip_stream) try {
     if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_db_set_stream: NULL handle");
     db->stream = hip_stream ? (hipStream_t)hip_stream : db->own_stream;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_db_set_stream");
 }
 
 void smafa_db_destroy(smafa_db *db) {
@@ -1429,27 +1443,33 @@ void smafa_db_destroy(smafa_db *db) {
     delete db;
 }
 
-int smafa_set_query_block(smafa_db *db, uint32_t queries_per_block) {
+int smafa_set_query_block(smafa_db *db, uint32_t queries_per_block) try {
     if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_set_query_block: NULL handle");
     db->qb_override = queries_per_block;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_set_query_block");
 }
 
-int smafa_last_scan_plan(smafa_db *db, uint32_t *filter_plane_resident, uint32_t *tiles_per_wave, uint32_t *query_blocks) {
+int smafa_last_scan_plan(smafa_db *db, uint32_t *filter_plane_resident, uint32_t *tiles_per_wave, uint32_t *query_blocks) try {
     if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_last_scan_plan: NULL handle");
     if (filter_plane_resident) *filter_plane_resident = db->plan_lazy;
     if (tiles_per_wave) *tiles_per_wave = db->plan_tiles;
     if (query_blocks) *query_blocks = db->plan_qblocks;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_last_scan_plan");
 }
 
-int smafa_last_scan_kernel(smafa_db *db, char *name, uint64_t cap) {
+int smafa_last_scan_kernel(smafa_db *db, char *name, uint64_t cap) try {
     if (!db || !name || cap == 0) return set_error(SMAFA_ERR_INVALID, "smafa_last_scan_kernel: NULL argument");
     snprintf(name, (size_t)cap, "%s", db->plan_kernel);
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_last_scan_kernel");
 }
 
-int smafa_hbm_read_probe(int device, uint64_t bytes, double *gb_per_s) {
+int smafa_hbm_read_probe(int device, uint64_t bytes, double *gb_per_s) try {
     if (!gb_per_s) return set_error(SMAFA_ERR_INVALID, "smafa_hbm_read_probe: NULL argument");
     *gb_per_s = 0.0;
     int ndev = 0;
@@ -1488,6 +1508,8 @@ int smafa_hbm_read_probe(int device, uint64_t bytes, double *gb_per_s) {
     if (e != hipSuccess) return set_error(SMAFA_ERR_DEVICE, "HBM read probe failed: %s", hipGetErrorString(e));
     if (best > 0.f) *gb_per_s = (double)bytes / ((double)best * 1e-3) / 1e9;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_hbm_read_probe");
 }
 
 const char *smafa_build_id(void) {
@@ -1498,19 +1520,23 @@ const char *smafa_build_id(void) {
 #endif
 }
 
-int smafa_set_zone_level(smafa_db *db, int mode) {
+int smafa_set_zone_level(smafa_db *db, int mode) try {
     if (!db || mode < 0 || mode > 2) return set_error(SMAFA_ERR_INVALID, "smafa_set_zone_level: bad argument");
     db->zone = mode;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_set_zone_level");
 }
 
-int smafa_set_prefilter(smafa_db *db, int enabled) {
+int smafa_set_prefilter(smafa_db *db, int enabled) try {
     if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_set_prefilter: NULL handle");
     db->use_filter = enabled != 0;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_set_prefilter");
 }
 
-int smafa_qset_create(smafa_qset **out, smafa_db *db, const uint8_t *query_codes, uint64_t n_queries) {
+int smafa_qset_create(smafa_qset **out, smafa_db *db, const uint8_t *query_codes, uint64_t n_queries) try {
     if (!out || !db || (!query_codes && n_queries)) return set_error(SMAFA_ERR_INVALID, "smafa_qset_create: NULL argument");
     *out = nullptr;
     if (n_queries > 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many queries in one set");
@@ -1526,6 +1552,8 @@ int smafa_qset_create(smafa_qset **out, smafa_db *db, const uint8_t *query_codes
     }
     *out = qs;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_qset_create");
 }
 
 void smafa_qset_destroy(smafa_qset *qs) {
@@ -1538,7 +1566,7 @@ void smafa_qset_destroy(smafa_qset *qs) {
 }
 
 int smafa_scan_launch(smafa_db *db, smafa_qset *qs, uint32_t max_div, uint32_t max_num_hits, void *d_hits,
-                      uint64_t cap, void *d_count) {
+                      uint64_t cap, void *d_count) try {
     if (!db || !qs || !d_count || (!d_hits && cap)) return set_error(SMAFA_ERR_INVALID, "smafa_scan_launch: NULL argument");
     if (qs->db != db) return set_error(SMAFA_ERR_INVALID, "query set was packed for a different store");
     if (max_num_hits == 0) max_num_hits = SMAFA_NONE;
@@ -1549,6 +1577,8 @@ int smafa_scan_launch(smafa_db *db, smafa_qset *qs, uint32_t max_div, uint32_t m
     if (!d_hits) d_hits = db->ctrs.p;
     return scan_range(db, qs, 0, (uint32_t)qs->nq, max_div, max_num_hits == SMAFA_NONE ? 0u : max_num_hits,
                       (smafa_hit *)d_hits, cap, (unsigned long long *)d_count);
+} catch (...) {
+    return smafa::exception_code("smafa_scan_launch");
 }
 
 // One pass over the store PER QUERY (north_star's literal "each query is broadcast against all subjects"), the passes
@@ -1558,7 +1588,7 @@ int smafa_scan_launch(smafa_db *db, smafa_qset *qs, uint32_t max_div, uint32_t m
 // use_graph: the passes are captured once as a HIP graph and replayed while the arguments stay the same — no launch
 // gap on the host side at all.
 int smafa_scan_each(smafa_db *db, smafa_qset *qs, uint32_t max_div, void *d_hits, uint64_t cap_per_query, void *d_counts,
-                    int use_graph) {
+                    int use_graph) try {
     if (!db || !qs || !d_counts || (!d_hits && cap_per_query)) return set_error(SMAFA_ERR_INVALID, "smafa_scan_each: NULL argument");
     if (qs->db != db) return set_error(SMAFA_ERR_INVALID, "query set was packed for a different store");
     int rc = use_device(db);
@@ -1622,23 +1652,29 @@ int smafa_scan_each(smafa_db *db, smafa_qset *qs, uint32_t max_div, void *d_hits
     HIP_TRY(hipEventRecord(db->ev1, db->stream));
     db->timed = true;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_scan_each");
 }
 
-int smafa_last_call_stats(smafa_db *db, float *kernel_ms, uint32_t *n_launches, uint32_t *n_scans) {
+int smafa_last_call_stats(smafa_db *db, float *kernel_ms, uint32_t *n_launches, uint32_t *n_scans) try {
     if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_last_call_stats: NULL handle");
     if (kernel_ms) *kernel_ms = db->call_ms;
     if (n_launches) *n_launches = db->call_launches;
     if (n_scans) *n_scans = db->call_scans;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_last_call_stats");
 }
 
-int smafa_sync(smafa_db *db) {
+int smafa_sync(smafa_db *db) try {
     if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_sync: NULL handle");
     HIP_TRY(hipStreamSynchronize(db->stream));
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_sync");
 }
 
-int smafa_last_scan_ms(smafa_db *db, float *ms, uint32_t *n_launches) {
+int smafa_last_scan_ms(smafa_db *db, float *ms, uint32_t *n_launches) try {
     if (!db || !ms) return set_error(SMAFA_ERR_INVALID, "smafa_last_scan_ms: NULL argument");
     *ms = 0.f;
     if (n_launches) *n_launches = db->last_launches;
@@ -1646,10 +1682,12 @@ int smafa_last_scan_ms(smafa_db *db, float *ms, uint32_t *n_launches) {
     HIP_TRY(hipEventSynchronize(db->ev1));
     HIP_TRY(hipEventElapsedTime(ms, db->ev0, db->ev1));
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_last_scan_ms");
 }
 
 int smafa_scan_hits(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div,
-                    uint32_t max_num_hits, smafa_hit *out, uint64_t cap, uint64_t *n_out) {
+                    uint32_t max_num_hits, smafa_hit *out, uint64_t cap, uint64_t *n_out) try {
     if (!db || !n_out || (!query_codes && n_queries) || (!out && cap))
         return set_error(SMAFA_ERR_INVALID, "smafa_scan_hits: NULL argument");
     if (max_num_hits == 0) max_num_hits = SMAFA_NONE;
@@ -1693,9 +1731,11 @@ int smafa_scan_hits(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries
     }
     if (!rows.empty()) memcpy(out, rows.data(), rows.size() * sizeof(smafa_hit));
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_scan_hits");
 }
 
-int smafa_distances(smafa_db *db, const uint8_t *query_codes, uint32_t *distances) {
+int smafa_distances(smafa_db *db, const uint8_t *query_codes, uint32_t *distances) try {
     if (!db || !query_codes || (!distances && db->n)) return set_error(SMAFA_ERR_INVALID, "smafa_distances: NULL argument");
     if (db->n == 0) return SMAFA_OK;
     int rc = use_device(db);
@@ -1714,6 +1754,8 @@ int smafa_distances(smafa_db *db, const uint8_t *query_codes, uint32_t *distance
     HIP_TRY(hipMemcpyAsync(distances, db->keys_a.p, db->n * sizeof(uint32_t), hipMemcpyDeviceToHost, db->stream));
     HIP_TRY(hipStreamSynchronize(db->stream));
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_distances");
 }
 
 }  // extern "C"

@@ -48,7 +48,7 @@ const char *alphabet_noun(int alphabet) { return alphabet == SMAFA_ALPHABET_AA ?
 
 extern "C" {
 
-int smafa_encode(int alphabet, const uint8_t *ascii, uint64_t len, uint8_t *codes, uint64_t *bad_pos) {
+int smafa_encode(int alphabet, const uint8_t *ascii, uint64_t len, uint8_t *codes, uint64_t *bad_pos) try {
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return smafa::set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
     if ((!ascii || !codes) && len) return smafa::set_error(SMAFA_ERR_INVALID, "smafa_encode: NULL argument");
@@ -63,9 +63,11 @@ int smafa_encode(int alphabet, const uint8_t *ascii, uint64_t len, uint8_t *code
         codes[i] = c;
     }
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_encode");
 }
 
-int smafa_decode(int alphabet, const uint8_t *codes, uint64_t len, char *out) {
+int smafa_decode(int alphabet, const uint8_t *codes, uint64_t len, char *out) try {
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return smafa::set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
     for (uint64_t i = 0; i < len; i++) {
@@ -74,6 +76,8 @@ int smafa_decode(int alphabet, const uint8_t *codes, uint64_t len, char *out) {
         out[i] = c;
     }
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_decode");
 }
 
 }

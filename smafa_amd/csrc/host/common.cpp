@@ -3,6 +3,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <ctime>
+#include <new>
+#include <stdexcept>
+#include <system_error>
 
 #include "../engine.h"
 
@@ -16,6 +19,22 @@ int set_error(int code, const char *fmt, ...) {
     vsnprintf(g_error, sizeof g_error, fmt, ap);
     va_end(ap);
     return code;
+}
+
+int exception_code(const char *where) noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return set_error(SMAFA_ERR_NOMEM, "%s: out of host memory", where);
+    } catch (const std::length_error &e) {
+        return set_error(SMAFA_ERR_NOMEM, "%s: out of host memory (%s)", where, e.what());
+    } catch (const std::system_error &e) {
+        return set_error(SMAFA_ERR_NOMEM, "%s: %s", where, e.what());
+    } catch (const std::exception &e) {
+        return set_error(SMAFA_ERR_INVALID, "%s: %s", where, e.what());
+    } catch (...) {
+        return set_error(SMAFA_ERR_INVALID, "%s: unknown failure", where);
+    }
 }
 
 static int g_verbosity = 0;

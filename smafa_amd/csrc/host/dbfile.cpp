@@ -111,7 +111,7 @@ using namespace smafa;
 
 extern "C" {
 
-int smafa_dbfile_write(const char *path, int alphabet, const uint8_t *codes, uint64_t n, uint32_t seq_len) {
+int smafa_dbfile_write(const char *path, int alphabet, const uint8_t *codes, uint64_t n, uint32_t seq_len) try {
     if (!path || (!codes && n)) return set_error(SMAFA_ERR_INVALID, "smafa_dbfile_write: NULL argument");
     std::vector<uint8_t> b;
     std::vector<std::vector<uint8_t>> parts;  // window bytes, one buffer per worker, in row order
@@ -187,9 +187,11 @@ int smafa_dbfile_write(const char *path, int alphabet, const uint8_t *codes, uin
     ok = ok && fwrite(tail.data(), 1, tail.size(), f) == tail.size();
     if (fclose(f) != 0 || !ok) return set_error(SMAFA_ERR_IO, "%s: write error", path);
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_dbfile_write");
 }
 
-int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t *n, uint32_t *seq_len) {
+int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t *n, uint32_t *seq_len) try {
     if (!path || !alphabet || !codes || !n || !seq_len) return set_error(SMAFA_ERR_INVALID, "smafa_dbfile_read: NULL argument");
     *codes = nullptr;
     *n = 0;
@@ -461,6 +463,8 @@ int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t
     *n = cnt;
     *seq_len = (uint32_t)L;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_dbfile_read");
 }
 
 }

@@ -223,7 +223,7 @@ extern "C" {
 // The records BEFORE the first offending one, and what is wrong with that one (*pending = 0 or the error code, its text in
 // smafa_last_error()): what a driver needs to print the rows the reference prints before it panics (src/lib.rs:232-318).
 int smafa_fastx_load_partial(const char *path, int alphabet, uint8_t **codes_out, uint64_t *n_out, uint32_t *seq_len,
-                             int *pending) {
+                             int *pending) try {
     if (!path || !codes_out || !n_out || !seq_len || !pending)
         return set_error(SMAFA_ERR_INVALID, "smafa_fastx_load_partial: NULL argument");
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
@@ -248,9 +248,11 @@ int smafa_fastx_load_partial(const char *path, int alphabet, uint8_t **codes_out
     else if (recs.err_kind == 3) *pending = set_error(SMAFA_ERR_PANIC, "Cannot add empty sequence to WindowSet");
     else if (recs.err_kind == 4) *pending = set_error(SMAFA_ERR_FORMAT, "%s", recs.err_msg.c_str());
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_fastx_load_partial");
 }
 
-int smafa_fastx_load(const char *path, int alphabet, uint8_t **codes_out, uint64_t *n_out, uint32_t *seq_len) {
+int smafa_fastx_load(const char *path, int alphabet, uint8_t **codes_out, uint64_t *n_out, uint32_t *seq_len) try {
     if (!path || !codes_out || !n_out || !seq_len) return set_error(SMAFA_ERR_INVALID, "smafa_fastx_load: NULL argument");
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
@@ -276,10 +278,12 @@ int smafa_fastx_load(const char *path, int alphabet, uint8_t **codes_out, uint64
     *n_out = n;
     *seq_len = (uint32_t)L;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_fastx_load");
 }
 
 // ------------------------------------------------------------------------------------- makedb
-int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet) {
+int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet) try {
     if (!subject_fasta || !db_path) return set_error(SMAFA_ERR_INVALID, "smafa_makedb: NULL path");
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
@@ -302,11 +306,13 @@ int smafa_makedb(const char *subject_fasta, const char *db_path, int alphabet) {
     if (rc == SMAFA_OK) log_line(1, "DB file written");
     log_line(2, "makedb: parse + encode %.2f s, serialise + write %.2f s", t_parsed - t_start, now_seconds() - t_parsed);
     return rc;
+} catch (...) {
+    return smafa::exception_code("smafa_makedb");
 }
 
 // makedb with the packed store file as output (host/packed.cpp): the same parse + encode, then the subjects are packed on
 // the device exactly as `query` would pack them, and the resident store is saved.
-int smafa_makedb_packed(const char *subject_fasta, const char *db_path, int alphabet, int device) {
+int smafa_makedb_packed(const char *subject_fasta, const char *db_path, int alphabet, int device) try {
     if (!subject_fasta || !db_path) return set_error(SMAFA_ERR_INVALID, "smafa_makedb_packed: NULL path");
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
@@ -342,6 +348,8 @@ int smafa_makedb_packed(const char *subject_fasta, const char *db_path, int alph
     log_line(2, "makedb --packed: parse + encode %.2f s (device ready %.2f s after start), pack on the device %.2f s, copy back + write %.2f s",
              t_parsed - t_start, t_ready - t_start, t_packed - t_ready, now_seconds() - t_packed);
     return rc;
+} catch (...) {
+    return smafa::exception_code("smafa_makedb_packed");
 }
 
 // -------------------------------------------------------------------------------------- query
@@ -350,7 +358,7 @@ int smafa_makedb_packed(const char *subject_fasta, const char *db_path, int alph
 // (src/lib.rs:232-318), so every chunk of queries is cut into ndev contiguous blocks, block g is scanned and selected by
 // host thread g on handle g, and the blocks' rows are printed in block order: the output does not depend on ndev.
 int smafa_query_multi(const char *db_path, const char *query_fasta, uint32_t max_divergence, uint32_t max_num_hits,
-                      uint32_t limit_per_sequence, int out_fd, const int *devices, int ndev) {
+                      uint32_t limit_per_sequence, int out_fd, const int *devices, int ndev) try {
     if (!db_path || !query_fasta) return set_error(SMAFA_ERR_INVALID, "smafa_query: NULL path");
     if (!devices || ndev < 1 || ndev > 64) return set_error(SMAFA_ERR_INVALID, "smafa_query_multi: 1 to 64 devices expected");
     int alphabet = 0;
@@ -561,11 +569,15 @@ int smafa_query_multi(const char *db_path, const char *query_fasta, uint32_t max
     log_line(2, "%u queries: scans + selection %.2f s on %d handle(s)", query_number, t_scan, ndev);
     log_line(1, "Querying complete, took %llu seconds", (unsigned long long)(now_seconds() - t_start));  // src/lib.rs:320-323
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_query_multi");
 }
 
 int smafa_query(const char *db_path, const char *query_fasta, uint32_t max_divergence, uint32_t max_num_hits,
-                uint32_t limit_per_sequence, int out_fd, int device) {
+                uint32_t limit_per_sequence, int out_fd, int device) try {
     return smafa_query_multi(db_path, query_fasta, max_divergence, max_num_hits, limit_per_sequence, out_fd, &device, 1);
+} catch (...) {
+    return smafa::exception_code("smafa_query");
 }
 
 // ------------------------------------------------------------------------------------ cluster
@@ -844,21 +856,25 @@ static int cluster_run(const ClusterInput &in, uint32_t max_divergence, int out_
     return SMAFA_OK;
 }
 
-int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet) {
+int smafa_cluster(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet) try {
     ClusterInput in;
     int rc = cluster_load(input_fasta, alphabet, device, in);
     if (rc) return rc;
     return cluster_run(in, max_divergence, out_fd, device, alphabet, 0, 1, nullptr, nullptr);
+} catch (...) {
+    return smafa::exception_code("smafa_cluster");
 }
 
 int smafa_cluster_sharded(const char *input_fasta, uint32_t max_divergence, int out_fd, int device, int alphabet,
-                          uint32_t rank, uint32_t world, smafa_allgather_fn allgather, void *ctx) {
+                          uint32_t rank, uint32_t world, smafa_allgather_fn allgather, void *ctx) try {
     if (world == 0 || rank >= world) return set_error(SMAFA_ERR_INVALID, "rank %u outside world of %u", rank, world);
     if (world > 1 && !allgather) return set_error(SMAFA_ERR_INVALID, "smafa_cluster_sharded: NULL allgather");
     ClusterInput in;
     int rc = cluster_load(input_fasta, alphabet, device, in);
     if (rc) return rc;
     return cluster_run(in, max_divergence, out_fd, device, alphabet, rank, world, allgather, ctx);
+} catch (...) {
+    return smafa::exception_code("smafa_cluster_sharded");
 }
 
 // ---- the same clustering over several GPUs of one node by ONE process: one host thread per entry of `devices` plays a
@@ -902,7 +918,7 @@ int thread_allgather(void *ctx, const void *send, uint64_t send_bytes, const voi
 }
 }  // namespace
 
-int smafa_cluster_multi(const char *input_fasta, uint32_t max_divergence, int out_fd, const int *devices, int ndev, int alphabet) {
+int smafa_cluster_multi(const char *input_fasta, uint32_t max_divergence, int out_fd, const int *devices, int ndev, int alphabet) try {
     if (!devices || ndev < 1 || ndev > 64) return set_error(SMAFA_ERR_INVALID, "smafa_cluster_multi: 1 to 64 devices expected");
     ClusterInput in;
     int rc = cluster_load(input_fasta, alphabet, devices[0], in);
@@ -934,11 +950,13 @@ int smafa_cluster_multi(const char *input_fasta, uint32_t max_divergence, int ou
     for (int r = 0; r < ndev; r++)
         if (rcs[r]) return set_error(rcs[r], "%s", msgs[r].c_str());
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_cluster_multi");
 }
 
 // ---------------------------------------------------------------------------------- write_rows
 int smafa_write_rows(const smafa_hit *rows, uint64_t n_rows, const uint8_t *subject_codes, uint64_t n_subjects,
-                     uint32_t seq_len, int alphabet, uint32_t query_offset, int out_fd) {
+                     uint32_t seq_len, int alphabet, uint32_t query_offset, int out_fd) try {
     if ((!rows && n_rows) || (!subject_codes && n_rows)) return set_error(SMAFA_ERR_INVALID, "smafa_write_rows: NULL argument");
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA)
         return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
@@ -950,10 +968,12 @@ int smafa_write_rows(const smafa_hit *rows, uint64_t n_rows, const uint8_t *subj
     subjects.codes = subject_codes;
     subjects.L = seq_len;
     return write_rows_text(rows, n_rows, subjects, alphabet, query_offset, out_fd);
+} catch (...) {
+    return smafa::exception_code("smafa_write_rows");
 }
 
 // -------------------------------------------------------------------------------------- count
-int smafa_count(const char *const *paths, uint64_t n_paths, int out_fd) {
+int smafa_count(const char *const *paths, uint64_t n_paths, int out_fd) try {
     std::string text = "[";
     for (uint64_t i = 0; i < n_paths; i++) {
         FastxReader reader;
@@ -976,6 +996,8 @@ int smafa_count(const char *const *paths, uint64_t n_paths, int out_fd) {
     }
     text += "]\n";
     return write_all(out_fd, text.data(), text.size());
+} catch (...) {
+    return smafa::exception_code("smafa_count");
 }
 
 }  // extern "C"

@@ -83,7 +83,7 @@ using namespace smafa;
 
 extern "C" {
 
-int smafa_group_create(smafa_group **out, const int *devices, int ndev, int alphabet, uint32_t seq_len) {
+int smafa_group_create(smafa_group **out, const int *devices, int ndev, int alphabet, uint32_t seq_len) try {
     int rc = group_alloc(out, devices, ndev);
     if (rc) return rc;
     smafa_group *grp = *out;
@@ -93,22 +93,28 @@ int smafa_group_create(smafa_group **out, const int *devices, int ndev, int alph
         *out = nullptr;
     }
     return rc;
+} catch (...) {
+    return smafa::exception_code("smafa_group_create");
 }
 
-int smafa_group_load(smafa_group **out, const int *devices, int ndev, const char *path) {
+int smafa_group_load(smafa_group **out, const int *devices, int ndev, const char *path) try {
     if (!path) return set_error(SMAFA_ERR_INVALID, "smafa_group_load: NULL path");
     if (out) *out = nullptr;
     PackedStore pk;
     int rc = pk.open(path);
     if (rc) return rc;
     return group_load_packed(out, devices, ndev, pk);
+} catch (...) {
+    return smafa::exception_code("smafa_group_load");
 }
 
-int smafa_group_append(smafa_group *grp, const uint8_t *codes, uint64_t n) {
+int smafa_group_append(smafa_group *grp, const uint8_t *codes, uint64_t n) try {
     if (!grp || (!codes && n)) return set_error(SMAFA_ERR_INVALID, "smafa_group_append: NULL argument");
     grp->generation++;
     // every replica receives the same rows in the same order: subject indices agree across the members
     return group_on_every_handle(grp, [&](int g) { return smafa_db_append(grp->dbs[g], codes, n); });
+} catch (...) {
+    return smafa::exception_code("smafa_group_append");
 }
 
 int smafa_group_size(const smafa_group *grp) { return grp ? (int)grp->dbs.size() : 0; }
@@ -119,7 +125,7 @@ smafa_db *smafa_group_member(smafa_group *grp, int index) {
 }
 
 int smafa_group_scan_hits(smafa_group *grp, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div,
-                          uint32_t max_num_hits, smafa_hit *out, uint64_t cap, uint64_t *n_out) {
+                          uint32_t max_num_hits, smafa_hit *out, uint64_t cap, uint64_t *n_out) try {
     if (!grp || !n_out || (!query_codes && n_queries) || (!out && cap))
         return set_error(SMAFA_ERR_INVALID, "smafa_group_scan_hits: NULL argument");
     if (n_queries > 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many queries in one batch");
@@ -167,6 +173,8 @@ int smafa_group_scan_hits(smafa_group *grp, const uint8_t *query_codes, uint64_t
     std::vector<uint8_t>().swap(grp->retry_codes);
     if (!rows.empty()) memcpy(out, rows.data(), rows.size() * sizeof(smafa_hit));
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_group_scan_hits");
 }
 
 void smafa_group_destroy(smafa_group *grp) {

@@ -37,7 +37,7 @@ using namespace smafa;
 extern "C" {
 
 int smafa_fastx_load_part(const char *path, int alphabet, uint32_t part, uint32_t parts, uint8_t **codes_out, uint64_t *n_out,
-                          uint32_t *seq_len, int *pending, int *usable) {
+                          uint32_t *seq_len, int *pending, int *usable) try {
     if (!path || !codes_out || !n_out || !seq_len || !pending || !usable)
         return set_error(SMAFA_ERR_INVALID, "smafa_fastx_load_part: NULL argument");
     if (alphabet != SMAFA_ALPHABET_NT && alphabet != SMAFA_ALPHABET_AA) return set_error(SMAFA_ERR_INVALID, "unknown alphabet %d", alphabet);
@@ -64,9 +64,11 @@ int smafa_fastx_load_part(const char *path, int alphabet, uint32_t part, uint32_
                              recs.err_len, recs.L);
     else if (recs.err_kind == 3) *pending = set_error(SMAFA_ERR_PANIC, "Cannot add empty sequence to WindowSet");
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_fastx_load_part");
 }
 
-int smafa_qsession_open(smafa_qsession **out, const char *db_path, int device) {
+int smafa_qsession_open(smafa_qsession **out, const char *db_path, int device) try {
     if (!out || !db_path) return set_error(SMAFA_ERR_INVALID, "smafa_qsession_open: NULL argument");
     *out = nullptr;
     smafa_qsession *s = new smafa_qsession();
@@ -105,19 +107,23 @@ int smafa_qsession_open(smafa_qsession **out, const char *db_path, int device) {
     s->subjects.L = s->L;
     *out = s;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_qsession_open");
 }
 
-int smafa_qsession_info(const smafa_qsession *s, uint64_t *n_subjects, uint32_t *seq_len, int *alphabet) {
+int smafa_qsession_info(const smafa_qsession *s, uint64_t *n_subjects, uint32_t *seq_len, int *alphabet) try {
     if (!s) return set_error(SMAFA_ERR_INVALID, "smafa_qsession_info: NULL session");
     if (n_subjects) *n_subjects = s->n;
     if (seq_len) *seq_len = s->L;
     if (alphabet) *alphabet = s->alphabet;
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_qsession_info");
 }
 
 int smafa_qsession_scan_part(smafa_qsession *s, const char *query_fasta, uint32_t max_divergence, uint32_t max_num_hits,
                              uint32_t limit_per_sequence, uint32_t part, uint32_t parts, int whole_file, smafa_hit **rows_out,
-                             uint64_t *n_rows, uint64_t *n_queries, uint64_t *n_before, int *pending, int *retry_whole) {
+                             uint64_t *n_rows, uint64_t *n_queries, uint64_t *n_before, int *pending, int *retry_whole) try {
     if (!s || !query_fasta || !rows_out || !n_rows || !n_queries || !n_before || !pending || !retry_whole)
         return set_error(SMAFA_ERR_INVALID, "smafa_qsession_scan_part: NULL argument");
     if (parts == 0 || part >= parts) return set_error(SMAFA_ERR_INVALID, "part %u of %u", part, parts);
@@ -209,15 +215,19 @@ int smafa_qsession_scan_part(smafa_qsession *s, const char *query_fasta, uint32_
     }
     if (*pending != SMAFA_OK) set_error(*pending, "%s", pending_msg.c_str());  // the text for the caller to relay
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_qsession_scan_part");
 }
 
-int smafa_qsession_write(smafa_qsession *s, const smafa_hit *rows, uint64_t n_rows, int out_fd) {
+int smafa_qsession_write(smafa_qsession *s, const smafa_hit *rows, uint64_t n_rows, int out_fd) try {
     if (!s || (!rows && n_rows)) return set_error(SMAFA_ERR_INVALID, "smafa_qsession_write: NULL argument");
     for (uint64_t i = 0; i < n_rows; i++)
         if (rows[i].subject >= s->n)
             return set_error(SMAFA_ERR_INVALID, "row %llu names subject %u of %llu", (unsigned long long)i, rows[i].subject,
                              (unsigned long long)s->n);
     return write_rows_text(rows, n_rows, s->subjects, s->alphabet, 0, out_fd);  // src/lib.rs:292,310
+} catch (...) {
+    return smafa::exception_code("smafa_qsession_write");
 }
 
 void smafa_qsession_close(smafa_qsession *s) {

@@ -82,7 +82,7 @@ int select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint
 extern "C" int smafa_select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_t n_queries, uint64_t n_subjects,
                                  const uint8_t *subject_codes, uint32_t seq_len, uint32_t max_div,
                                  uint32_t max_num_hits, uint32_t limit_per_sequence, smafa_hit *rows, uint64_t cap,
-                                 uint64_t *n_rows) {
+                                 uint64_t *n_rows) try {
     if (!n_rows || (!hits && n_hits) || (!rows && cap)) return smafa::set_error(SMAFA_ERR_INVALID, "smafa_select_rows: NULL argument");
     std::vector<smafa_hit> out;
     smafa::SubjectRows subjects;
@@ -95,4 +95,6 @@ extern "C" int smafa_select_rows(const smafa_hit *hits, uint64_t n_hits, uint64_
         return smafa::set_error(SMAFA_ERR_CAPACITY, "row buffer too small: %zu rows needed", out.size());
     if (!out.empty()) memcpy(rows, out.data(), out.size() * sizeof(smafa_hit));
     return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_select_rows");
 }

@@ -1684,8 +1684,8 @@ __global__ __launch_bounds__(256, 4) void scan_wide_kernel(const uint4 *__restri
                     uint32_t qf[NF];
                     qf[0] = qw0;
                     qf[1] = ONE ? head.z : head.y;
-                    if (NF >= 3) qf[2] = head.w;
-                    if (NF >= 4) qf[3] = heads[buf][i][HV - 1].x;
+                    if (NF >= 3) qf[NF >= 3 ? 2 : 0] = head.w;
+                    if (NF >= 4) qf[NF >= 4 ? 3 : 0] = heads[buf][i][HV - 1].x;
 #pragma unroll
                     for (int t = 0; t < T; t++) {
                         if (GATED && !((tiles >> t) & 1u)) continue;

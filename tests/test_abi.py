@@ -544,3 +544,38 @@ def test_bzip2_and_xz_inputs(tmp_path, kind):
     r = cli("makedb", "-i", packed, "-d", db_b)
     assert r.returncode == 101 and ("truncated" in r.stderr or "damaged" in r.stderr), r.stderr  # .expect(..): src/lib.rs:144
     assert cli("count", "-i", packed).returncode == 1  # `?`: src/lib.rs:381
+
+
+def test_allocation_failure_is_an_error_code_not_an_exception_through_the_c_abi(tmp_path):
+    """every int-returning entry point is a function-try-block: std::bad_alloc inside the call comes back as
+    SMAFA_ERR_NOMEM with a message, the process lives, and the same call succeeds once memory is there.  (A subprocess,
+    because the address-space limit that provokes the failure cannot be taken back.)"""
+    import subprocess
+    import sys
+
+    prog = r"""
+import ctypes as C, os, resource, sys
+import numpy as np
+sys.path.insert(0, %r)
+from smafa_amd import _lib
+lib = _lib.lib()
+path = os.path.join(%r, "s.fna")
+rng = np.random.default_rng(1)
+rec = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(300000, 60))]
+with open(path, "wb") as f:
+    for i in range(0, len(rec), 10000):
+        f.write(b"".join(b">r\n" + bytes(r) + b"\n" for r in rec[i:i + 10000]))
+vm = int([l for l in open("/proc/self/status") if l.startswith("VmSize")][0].split()[1]) * 1024
+out = []
+for extra in (4 << 20, 1 << 30):
+    resource.setrlimit(resource.RLIMIT_AS, (vm + extra, resource.RLIM_INFINITY))
+    codes, n, L = C.c_void_p(), C.c_uint64(), C.c_uint32()
+    rc = lib.smafa_fastx_load(path.encode(), 0, C.byref(codes), C.byref(n), C.byref(L))
+    out.append((rc, n.value, lib.smafa_last_error().decode() if rc else ""))
+print(out)
+""" % (ROOT, str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = eval(r.stdout.strip().splitlines()[-1])
+    assert got[0][0] == _lib.ERR_NOMEM == -7 and "out of host memory" in got[0][2] and got[0][1] == 0
+    assert got[1][0] == 0 and got[1][1] == 300000
