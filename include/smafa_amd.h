@@ -200,7 +200,8 @@ int smafa_group_append(smafa_group *grp, const uint8_t *codes, uint64_t n);
 int smafa_group_scan_hits(smafa_group *grp, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div,
                           uint32_t max_num_hits, smafa_hit *out, uint64_t cap, uint64_t *n_out);
 int smafa_group_size(const smafa_group *grp);
-/* member `index` (borrowed; owned by the group): for smafa_db_info, the tuning knobs, or device-resident launches */
+/* member `index` (borrowed; owned by the group): for smafa_db_info, the tuning knobs, or device-resident launches.
+ * Rows are appended through smafa_group_append only (the replicas must stay identical); never destroy a member. */
 smafa_db *smafa_group_member(smafa_group *grp, int index);
 void smafa_group_destroy(smafa_group *grp); /* NULL-safe */
 

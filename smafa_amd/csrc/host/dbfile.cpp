@@ -217,7 +217,7 @@ int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t
         if (rc) return rc;
         const uint64_t cnt = pk.h.n, len = pk.h.seq_len;
         uint8_t *out = (uint8_t *)malloc(std::max<size_t>(cnt * len, 1));
-        if (!out) return set_error(SMAFA_ERR_IO, "out of memory");
+        if (!out) return set_error(SMAFA_ERR_NOMEM, "out of host memory");
         const unsigned T = cnt >= (1u << 16) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
         std::vector<int> rcs(T, SMAFA_OK);
         std::vector<std::string> msgs(T);
@@ -252,7 +252,7 @@ int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t
             (buf.size() - pos) / len < cnt)
             return set_error(SMAFA_ERR_FORMAT, "%s: malformed version-3 store", path);
         uint8_t *out = (uint8_t *)malloc(std::max<size_t>(cnt * len, 1));
-        if (!out) return set_error(SMAFA_ERR_IO, "out of memory");
+        if (!out) return set_error(SMAFA_ERR_NOMEM, "out of host memory");
         memcpy(out, buf.data() + pos, cnt * len);
         for (size_t i = 0; i < cnt * len; i++)
             if (out[i] >= 28) {
@@ -405,7 +405,7 @@ int smafa_dbfile_read(const char *path, int *alphabet, uint8_t **codes, uint64_t
         }
     } onehot;
     uint8_t *wide = (uint8_t *)malloc(std::max<size_t>((size_t)cnt * stride, 1));
-    if (!wide) return set_error(SMAFA_ERR_IO, "out of memory");
+    if (!wide) return set_error(SMAFA_ERR_NOMEM, "out of host memory");
     std::vector<int> bad_symbol(spans.size(), -1);  // per span: offending 5-bit value, or -1
     auto decode = [&](size_t si) {
         const Span &sp = spans[si];

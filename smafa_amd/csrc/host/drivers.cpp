@@ -236,7 +236,7 @@ int smafa_fastx_load_partial(const char *path, int alphabet, uint8_t **codes_out
     int rc = load_records_bulk(path, alphabet, false, recs);
     if (rc) return rc;
     uint8_t *out = (uint8_t *)malloc(recs.codes.empty() ? 1 : recs.codes.size());
-    if (!out) return set_error(SMAFA_ERR_IO, "out of memory");
+    if (!out) return set_error(SMAFA_ERR_NOMEM, "out of host memory");
     if (!recs.codes.empty()) memcpy(out, recs.codes.data(), recs.codes.size());
     *codes_out = out;
     *n_out = recs.n;
@@ -272,7 +272,7 @@ int smafa_fastx_load(const char *path, int alphabet, uint8_t **codes_out, uint64
     const uint64_t n = recs.n;
     const size_t L = recs.L;
     uint8_t *out = (uint8_t *)malloc(codes.empty() ? 1 : codes.size());
-    if (!out) return set_error(SMAFA_ERR_IO, "out of memory");
+    if (!out) return set_error(SMAFA_ERR_NOMEM, "out of host memory");
     if (!codes.empty()) memcpy(out, codes.data(), codes.size());
     *codes_out = out;
     *n_out = n;

@@ -94,6 +94,10 @@ int smafa_group_create(smafa_group **out, const int *devices, int ndev, int alph
     }
     return rc;
 } catch (...) {
+    if (out && *out) {  // a group half built when the exception came
+        smafa_group_destroy(*out);
+        *out = nullptr;
+    }
     return smafa::exception_code("smafa_group_create");
 }
 
@@ -105,6 +109,10 @@ int smafa_group_load(smafa_group **out, const int *devices, int ndev, const char
     if (rc) return rc;
     return group_load_packed(out, devices, ndev, pk);
 } catch (...) {
+    if (out && *out) {  // a group half built when the exception came
+        smafa_group_destroy(*out);
+        *out = nullptr;
+    }
     return smafa::exception_code("smafa_group_load");
 }
 

@@ -13,6 +13,7 @@
 // (the caller drops the rows of the ranks after the first one that reports *pending != 0).
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -33,7 +34,6 @@ struct smafa_qsession {
 
 using namespace smafa;
 
-
 extern "C" {
 
 int smafa_fastx_load_part(const char *path, int alphabet, uint32_t part, uint32_t parts, uint8_t **codes_out, uint64_t *n_out,
@@ -53,7 +53,7 @@ int smafa_fastx_load_part(const char *path, int alphabet, uint32_t part, uint32_
     if (!ok) return SMAFA_OK;
     *usable = 1;
     uint8_t *out = (uint8_t *)malloc(recs.codes.empty() ? 1 : recs.codes.size());
-    if (!out) return set_error(SMAFA_ERR_IO, "out of memory");
+    if (!out) return set_error(SMAFA_ERR_NOMEM, "out of host memory");
     if (!recs.codes.empty()) memcpy(out, recs.codes.data(), recs.codes.size());
     *codes_out = out;
     *n_out = recs.n;
@@ -71,11 +71,12 @@ int smafa_fastx_load_part(const char *path, int alphabet, uint32_t part, uint32_
 int smafa_qsession_open(smafa_qsession **out, const char *db_path, int device) try {
     if (!out || !db_path) return set_error(SMAFA_ERR_INVALID, "smafa_qsession_open: NULL argument");
     *out = nullptr;
-    smafa_qsession *s = new smafa_qsession();
-    auto fail = [&](int rc) {
-        smafa_qsession_close(s);
-        return rc;
+    struct Closer {
+        void operator()(smafa_qsession *q) const { smafa_qsession_close(q); }
     };
+    std::unique_ptr<smafa_qsession, Closer> owner(new smafa_qsession());  // closed on every early return and on an exception
+    smafa_qsession *s = owner.get();
+    auto fail = [&](int rc) { return rc; };
     uint8_t head[8] = {0};
     if (FILE *f = fopen(db_path, "rb")) {
         const size_t got = fread(head, 1, sizeof head, f);
@@ -105,7 +106,7 @@ int smafa_qsession_open(smafa_qsession **out, const char *db_path, int device) t
     s->subjects.codes = s->codes;
     s->subjects.packed = s->packed ? &s->pk : nullptr;
     s->subjects.L = s->L;
-    *out = s;
+    *out = owner.release();
     return SMAFA_OK;
 } catch (...) {
     return smafa::exception_code("smafa_qsession_open");
@@ -208,7 +209,7 @@ int smafa_qsession_scan_part(smafa_qsession *s, const char *query_fasta, uint32_
     }
     if (!rows.empty()) {
         smafa_hit *p = (smafa_hit *)malloc(rows.size() * sizeof(smafa_hit));
-        if (!p) return set_error(SMAFA_ERR_IO, "out of memory");
+        if (!p) return set_error(SMAFA_ERR_NOMEM, "out of host memory");
         memcpy(p, rows.data(), rows.size() * sizeof(smafa_hit));
         *rows_out = p;
         *n_rows = rows.size();
