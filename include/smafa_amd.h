@@ -76,7 +76,8 @@ void smafa_set_verbosity(int level);
  * whether a committed counter profile belongs to the binary it is timing). */
 const char *smafa_build_id(void);
 /* Measurement helper: the device's empirical HBM read-stream rate in GB/s — a trivial sum kernel over
- * `bytes` (use >= 4 GiB: far more than the 256 MiB Infinity Cache), best of a few repetitions. */
+ * `bytes` (use >= 4 GiB: far more than the 256 MiB Infinity Cache), best of a few repetitions and of two read forms
+ * (grid-stride default-policy loads; one contiguous span per workgroup with non-temporal loads). */
 int smafa_hbm_read_probe(int device, uint64_t bytes, double *gb_per_s);
 
 /* ----------------------------------------------------------------- encoding */

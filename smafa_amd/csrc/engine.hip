@@ -130,6 +130,7 @@ struct smafa_db {
     smafa_qset scratch_q3;    // the sample of open queries the later steps of the ladder are planned from
     bool two_phase = true;    // near-hit probe before the tightening path (SMAFA_TWO_PHASE=0 disables)
     bool fold3 = true;        // scan_kernel's all-planes-but-the-last bound for launches whose bound starts above 32 (SMAFA_FOLD3=0)
+    bool stream_nt = true;    // one-query-block launches of scan_lazy_kernel load their filter words non-temporally (SMAFA_STREAM_NT=0)
     uint32_t count_first_k = 3;  // smallest k whose loose-bound scans count first and append second (SMAFA_COUNT_FIRST_K)
     // rows of a smafa_scan_hits call that ended in SMAFA_ERR_CAPACITY, kept for the caller's "grow and retry":
     // the retry with the same arguments against the same store is answered without scanning again
@@ -699,6 +700,7 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     a.zone = db->d_zone;
     a.zone_on = (wide && !zone && !seed && db->W > 4 && zone_pays(db, thr0, true)) ? 1u : 0u;
     const uint64_t n_qblocks = (q_end - q_begin + a.qb_size - 1) / a.qb_size;
+    a.stream_once = (n_qblocks == 1 && db->stream_nt) ? 1u : 0u;
     const uint64_t grid = n_qblocks * a.n_wg_tiles;
     if (grid > 0x7fffffffull)
         return set_error(SMAFA_ERR_INVALID, "scan grid too large (%llu workgroups)", (unsigned long long)grid);
@@ -1297,6 +1299,7 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     if (const char *lv = getenv("SMAFA_LAZY")) db->lazy = atoi(lv) != 0;
     if (const char *pv2 = getenv("SMAFA_TWO_PHASE")) db->two_phase = atoi(pv2) != 0;
     if (const char *f3 = getenv("SMAFA_FOLD3")) db->fold3 = atoi(f3) != 0;
+    if (const char *sn = getenv("SMAFA_STREAM_NT")) db->stream_nt = atoi(sn) != 0;
     if (const char *cv = getenv("SMAFA_COUNT_FIRST_K")) db->count_first_k = (uint32_t)std::max(2, atoi(cv));
     if (const char *ov = getenv("SMAFA_WIDE_ONE")) db->wide_one = atoi(ov) != 0;
     if (const char *wv = getenv("SMAFA_WIDE_FROM")) db->wide_from = (uint32_t)std::max(3, atoi(wv));
@@ -1489,11 +1492,14 @@ int smafa_hbm_read_probe(int device, uint64_t bytes, double *gb_per_s) try {
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     float best = 0.f;
-    for (int per_cu : {8, 32}) {
-        const int grid = prop.multiProcessorCount * per_cu;
+    for (int shape = 0; shape < 4; shape++) {  // grid-stride at 8 and 32 workgroups per CU, then contiguous spans + nt at 8 and 16
+        const int grid = prop.multiProcessorCount * (shape == 0 ? 8 : shape == 1 ? 32 : shape == 2 ? 8 : 16);
         for (int rep = 0; rep < 4 && e == hipSuccess; rep++) {  // the first repetition of each shape warms up
             e = hipEventRecord(e0, nullptr);
-            hipLaunchKernelGGL(hbm_read_probe_kernel, dim3(grid), dim3(256), 0, nullptr, d, (size_t)(bytes / 16), out);
+            if (shape < 2)
+                hipLaunchKernelGGL(hbm_read_probe_kernel, dim3(grid), dim3(256), 0, nullptr, d, (size_t)(bytes / 16), out);
+            else
+                hipLaunchKernelGGL(hbm_read_probe_span_kernel, dim3(grid), dim3(256), 0, nullptr, d, (size_t)(bytes / 16), out);
             if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
             if (e == hipSuccess) e = hipEventSynchronize(e1);
             float ms = 0.f;

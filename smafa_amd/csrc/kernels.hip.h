@@ -119,6 +119,10 @@ struct ScanArgs {
     const uint4 *zone;          // per wave tile: {bits all its subjects share in filter word 0, which bits those are,
                                 //                 the same for word 1} — see zone_kernel
     uint32_t zone_on;           // scan_wide_kernel: apply the zone level (the store is sorted well enough for it to pay)
+    uint32_t stream_once;       // the launch has ONE query block: every store byte it touches is read once — scan_lazy_kernel
+                                // then loads its filter words with the non-temporal hint (no cache line is kept for a
+                                // re-read that never comes): 66.7 -> 60.6 us per pass over the 50M store's 400 MB plane
+                                // (0.74 -> 0.82 of 8 TB/s), 14.0 -> 13.1 us on the 10M store (profiles/r03_stream_nt.txt)
 };
 
 // Where a workgroup parks qualifying rows between two flushes: one buffer per chunk parity, so that the rows of
@@ -135,6 +139,12 @@ using RowStage = RowStageT<kStageRows>;
 // acc | (s ^ q) in one VALU op.  Truth table over (a=0xF0, b=0xCC, c=0xAA): 0xF0 | (0xCC ^ 0xAA) = 0xF6.
 __device__ __forceinline__ uint32_t or_xor(uint32_t acc, uint32_t s, uint32_t q) {
     return __builtin_amdgcn_bitop3_b32(acc, s, q, 0xF6);
+}
+// a 16-byte load with the non-temporal hint (global_load_dwordx4 ... nt): for bytes a launch reads exactly once
+__device__ __forceinline__ uint4 ld_nt(const uint4 *p) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 // a | b | c through the fast bitop3 path (v_or3_b32 itself issues at the slow rate)
 __device__ __forceinline__ uint32_t or3(uint32_t a, uint32_t b, uint32_t c) {
@@ -650,11 +660,12 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
     // filter-plane words of this lane's 4*T subjects; tile slots past the range hold a copy of tile_begin
     // (valid memory) and are ignored wherever rows could come out of them
     uint4 f[T][W];
+    const bool stream_once = a.stream_once != 0;  // (wave-uniform)
     auto load_filter = [&](int t) {
         const bool live = tile0 + t < a.tile_end;
         const uint4 *src = planes + (size_t)(live ? tile0 + t : a.tile_begin) * (PS * W * 64) + lane;
 #pragma unroll
-        for (int w = 0; w < W; w++) f[t][w] = src[(FP * W + w) * 64];
+        for (int w = 0; w < W; w++) f[t][w] = stream_once ? ld_nt(src + (FP * W + w) * 64) : src[(FP * W + w) * 64];
     };
 #pragma unroll
     for (int t = 0; t < T; t++) load_filter(t);
@@ -2134,6 +2145,24 @@ __global__ __launch_bounds__(256) void hbm_read_probe_kernel(const uint4 *__rest
     }
     for (; i < n; i += stride) acc += p[i].x;
     if (acc == 0x12345678u) out[0] = acc;  // keeps the loads alive
+}
+
+// The same bytes the way a streaming scan reads them at its best: every workgroup owns one contiguous span, loads carry the
+// non-temporal hint (tools/experiments/ubench_stream.hip: 0.87 of 8 TB/s against 0.63-0.76 for the grid-stride form above)
+__global__ __launch_bounds__(256) void hbm_read_probe_span_kernel(const uint4 *__restrict__ p, size_t n, uint32_t *out) {
+    const size_t per = (n + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t acc = 0;
+    size_t i = lo + threadIdx.x;
+    for (; i + 3 * 256 < hi; i += 4 * 256) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = ld_nt(p + i + u * 256);
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < hi; i += 256) acc += p[i].x;
+    if (acc == 0x12345678u) out[0] = acc;
 }
 
 __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint64_t n) {

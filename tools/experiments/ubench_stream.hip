@@ -1,0 +1,127 @@
+// ubench_stream.hip — how fast can ONE pass over a 400 MB plane (the 50M store's filter plane; larger than the 256 MB
+// Infinity Cache) be read, back to back, by load form?  Decides whether the one-query streaming pass (scan_lazy_kernel) can
+// go past the 0.70-0.74 of peak it shares with the trivial grid-stride read.
+//   hipcc -O3 --offload-arch=gfx950 -o /tmp/ubench_stream tools/experiments/ubench_stream.hip && /tmp/ubench_stream
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define CK(x)                                                                       \
+    do {                                                                            \
+        hipError_t e_ = (x);                                                        \
+        if (e_ != hipSuccess) {                                                     \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                 \
+            return 1;                                                               \
+        }                                                                           \
+    } while (0)
+
+template <bool NT>
+__device__ __forceinline__ uint4 ld(const uint4 *p) {
+    if (NT) {  // global_load_dwordx4 ... nt
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+
+// grid-stride, U loads in flight per lane
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_stride(const uint4 *__restrict__ p, size_t n, uint32_t *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = ld<NT>(p + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < n; i += stride) acc += p[i].x;
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+// every workgroup owns ONE contiguous span (what a tile-per-wave scan does): U x 4 KB in flight per workgroup
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_span(const uint4 *__restrict__ p, size_t n, uint32_t *out) {
+    const size_t per = (n + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t acc = 0;
+    size_t i = lo + threadIdx.x;
+    for (; i + (U - 1) * 256 < hi; i += U * 256) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = ld<NT>(p + i + u * 256);
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < hi; i += 256) acc += p[i].x;
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+// LDS-DMA: global -> LDS without a register hop, a ring of R x 4 KB per workgroup, nothing consumed but one word per slot
+template <int R, bool NT>
+__global__ __launch_bounds__(256) void k_dma(const uint4 *__restrict__ p, size_t n, uint32_t *out) {
+    __shared__ uint4 ring[R][256];
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t acc = 0;
+    for (; i + (R - 1) * stride + 256 <= n; i += R * stride) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p + i + r * stride + threadIdx.x),
+                                             (__attribute__((address_space(3))) void *)(&ring[r][wave * 64]), 16, 0, NT ? 2 : 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < R; r++) acc += ring[r][threadIdx.x].x;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const size_t bytes = 400001024, n = bytes / 16;
+    uint4 *d = nullptr;
+    uint32_t *out = nullptr;
+    CK(hipMalloc(&d, bytes));
+    CK(hipMalloc(&out, 4));
+    CK(hipMemset(d, 1, bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int cus = prop.multiProcessorCount;
+    auto run = [&](const char *name, auto launch) -> int {
+        for (int per_cu : {4, 8, 16, 32}) {
+            const int grid = cus * per_cu;
+            for (int i = 0; i < 5; i++) launch(grid);  // warm-up
+            CK(hipEventRecord(e0, nullptr));
+            const int passes = 100;
+            for (int i = 0; i < passes; i++) launch(grid);  // back to back, like smafa_scan_each
+            CK(hipEventRecord(e1, nullptr));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double gbs = (double)bytes * passes / (ms * 1e-3) / 1e9;
+            printf("%-28s %2d WG/CU  %7.2f us/pass  %6.0f GB/s  %.3f of 8 TB/s\n", name, per_cu, ms * 1e3 / passes, gbs, gbs / 8000.0);
+        }
+        return 0;
+    };
+#define RUN(name, kern) \
+    if (run(name, [&](int grid) { hipLaunchKernelGGL((kern), dim3(grid), dim3(256), 0, nullptr, d, n, out); })) return 1;
+    RUN("stride U=8", (k_stride<8, false>))
+    RUN("stride U=8 nt", (k_stride<8, true>))
+    RUN("stride U=4 nt", (k_stride<4, true>))
+    RUN("stride U=16 nt", (k_stride<16, true>))
+    RUN("span U=4", (k_span<4, false>))
+    RUN("span U=4 nt", (k_span<4, true>))
+    RUN("span U=8 nt", (k_span<8, true>))
+    RUN("lds-dma ring 4", (k_dma<4, false>))
+    RUN("lds-dma ring 4 nt", (k_dma<4, true>))
+    RUN("lds-dma ring 8 nt", (k_dma<8, true>))
+    return 0;
+}
