@@ -82,6 +82,25 @@ __global__ __launch_bounds__(256) void k_dma(const uint4 *__restrict__ p, size_t
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// the scan's own pattern: a wave reads the 2 KB of filter words inside each of its 4 tiles' 10 KB records (tile-major store)
+template <bool NT>
+__global__ __launch_bounds__(256) void k_tiles(const uint4 *__restrict__ p, size_t n_tiles, uint32_t *out) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const size_t tile0 = ((size_t)blockIdx.x * 4 + wave) * 4;
+    uint32_t acc = 0;
+    uint4 v[8];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const size_t tile = tile0 + t < n_tiles ? tile0 + t : 0;
+        const uint4 *src = p + tile * 640 + 4 * 2 * 64 + lane;  // 10 planes-words x 64 lanes per tile; the filter plane's two words
+        v[2 * t] = ld<NT>(src);
+        v[2 * t + 1] = ld<NT>(src + 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 int main() {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
@@ -123,5 +142,31 @@ int main() {
     RUN("lds-dma ring 4", (k_dma<4, false>))
     RUN("lds-dma ring 4 nt", (k_dma<4, true>))
     RUN("lds-dma ring 8 nt", (k_dma<8, true>))
+    {  // tile-major store of 50M subjects: 195 313 tiles x 10 KB = 2 GB, of which 400 MB are read
+        const size_t n_tiles = (50000000 + 255) / 256;
+        uint4 *big = nullptr;
+        CK(hipMalloc(&big, n_tiles * 10240));
+        CK(hipMemset(big, 1, n_tiles * 10240));
+        const int grid = (int)((n_tiles + 15) / 16);
+        for (int nt = 0; nt < 2; nt++) {
+            for (int rep = 0; rep < 2; rep++) {
+                for (int i = 0; i < 5; i++) {
+                    if (nt) hipLaunchKernelGGL((k_tiles<true>), dim3(grid), dim3(256), 0, nullptr, big, n_tiles, out);
+                    else hipLaunchKernelGGL((k_tiles<false>), dim3(grid), dim3(256), 0, nullptr, big, n_tiles, out);
+                }
+                CK(hipEventRecord(e0, nullptr));
+                for (int i = 0; i < 100; i++) {
+                    if (nt) hipLaunchKernelGGL((k_tiles<true>), dim3(grid), dim3(256), 0, nullptr, big, n_tiles, out);
+                    else hipLaunchKernelGGL((k_tiles<false>), dim3(grid), dim3(256), 0, nullptr, big, n_tiles, out);
+                }
+                CK(hipEventRecord(e1, nullptr));
+                CK(hipEventSynchronize(e1));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                const double gbs = (double)n_tiles * 2048 * 100 / (ms * 1e-3) / 1e9;
+                printf("%-28s one wave per 4 tiles  %7.2f us/pass  %6.0f GB/s  %.3f of 8 TB/s\n", nt ? "2 KB of every 10 KB, nt" : "2 KB of every 10 KB", ms * 1e3 / 100, gbs, gbs / 8000.0);
+            }
+        }
+    }
     return 0;
 }
