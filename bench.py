@@ -710,6 +710,29 @@ def main() -> int:
         k_s1, kern_s, plan_s = one_kernel()
         rows_s = counts_k.cpu().numpy().copy()
         hs = hits_k.cpu().numpy().view(np.uint32).reshape(K, cap_q, 3)
+        # (c) the same K passes as ONE launch: query blocks of one query (smafa_set_query_block 1) — the grid walks the query
+        #     list workgroup after workgroup, every query still streams the whole plane, no kernel boundary between two passes
+        big = torch.zeros(K * cap_q * 3, dtype=torch.int32, device=dev)
+        total = torch.zeros(1, dtype=torch.int64, device=dev)
+        the_store.set_query_block(1)
+        wall_1 = None
+        for rep in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            the_store.scan_launch(qs_k, D, None, big.data_ptr(), K * cap_q, total.data_ptr())
+            e1.record(stream)
+            torch.cuda.synchronize()
+            if rep:
+                w = e0.elapsed_time(e1) / K
+                wall_1 = w if wall_1 is None else min(wall_1, w)
+        plan_1, kern_1 = the_store.last_scan_plan(), the_store.last_scan_kernel()
+        the_store.set_query_block(args.query_block or 0)
+        n_1 = int(total.item())
+        rows_1 = sorted_rows(big[: 3 * n_1].cpu().numpy().view(np.uint32).reshape(-1, 3))
+        per_pass = [hs[i, : rows_s[i]].copy() for i in range(K)]
+        for i, r in enumerate(per_pass):
+            r[:, 0] = i  # scan_each numbers a pass's rows by the query's index in the set, as the one launch does
+        same_1 = n_1 == int(rows_s.sum()) and rows_1.tobytes() == sorted_rows(np.concatenate(per_pass)).tobytes()
         the_store.set_zone_level(1)
         same = bool((rows_z == rows_s).all()) and all(
             sorted_rows(hz[i, : rows_z[i]]).tobytes() == sorted_rows(hs[i, : rows_s[i]]).tobytes() for i in range(K))
@@ -736,7 +759,14 @@ def main() -> int:
                           "algorithmic_x_of_peak": alg / k_s1 / 1e6 / HBM_PEAK_GBS,
                           "kernel_streamed_GBs": streamed / k_s1 / 1e6, "wall_streamed_GBs": streamed / wall_s / 1e6,
                           "rows": int(rows_s.sum())},
-            "rows_identical": same,
+            "streaming_one_launch": {"kernel": kern_1, "query_blocks": plan_1["query_blocks"], "ms_per_query_wall": wall_1,
+                                     "frac_wall_streamed": streamed / wall_1 / 1e6 / HBM_PEAK_GBS,
+                                     "wall_streamed_GBs": streamed / wall_1 / 1e6, "rows": n_1,
+                                     "rows_identical_to_the_passes": same_1,
+                                     "note": "the same passes as ONE launch with query blocks of one query "
+                                             "(smafa_set_query_block 1): every query streams the whole plane, no kernel "
+                                             "boundary between two passes; rows of all queries in one list"},
+            "rows_identical": same and same_1,
             "trivial_read_of_the_streamed_bytes_GBs": ceiling_same,
             "streaming_kernel_vs_trivial_read_of_the_same_bytes": (streamed / k_s1 / 1e6) / ceiling_same if ceiling_same else None,
         }
@@ -935,6 +965,7 @@ def main() -> int:
                                    "achieved": best["streaming"]["kernel_streamed_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": best["streaming"]["frac_kernel_streamed"],
                                    "frac_wall": best["streaming"]["frac_wall_streamed"],
+                                   "frac_wall_one_launch": best["streaming_one_launch"]["frac_wall_streamed"],
                                    "traffic": best["streamed_bytes_per_pass"], "store": best["store"], "served_by": best["served_by"]}
 
     if rank == 0:

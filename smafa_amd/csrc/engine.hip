@@ -700,7 +700,10 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     a.zone = db->d_zone;
     a.zone_on = (wide && !zone && !seed && db->W > 4 && zone_pays(db, thr0, true)) ? 1u : 0u;
     const uint64_t n_qblocks = (q_end - q_begin + a.qb_size - 1) / a.qb_size;
-    a.stream_once = (n_qblocks == 1 && db->stream_nt) ? 1u : 0u;
+    // non-temporal filter loads (scan_lazy_kernel): where a cached copy is never read again — one query block, or a filter
+    // plane of the range too big for the 256 MiB Infinity Cache to hold until the next query block comes round
+    const uint64_t range_filter_bytes = (uint64_t)(tile_end - tile_begin) * db->W * 1024u;
+    a.stream_once = (db->stream_nt && (n_qblocks == 1 || range_filter_bytes >= (256ull << 20))) ? 1u : 0u;
     const uint64_t grid = n_qblocks * a.n_wg_tiles;
     if (grid > 0x7fffffffull)
         return set_error(SMAFA_ERR_INVALID, "scan grid too large (%llu workgroups)", (unsigned long long)grid);

@@ -119,7 +119,8 @@ struct ScanArgs {
     const uint4 *zone;          // per wave tile: {bits all its subjects share in filter word 0, which bits those are,
                                 //                 the same for word 1} — see zone_kernel
     uint32_t zone_on;           // scan_wide_kernel: apply the zone level (the store is sorted well enough for it to pay)
-    uint32_t stream_once;       // the launch has ONE query block: every store byte it touches is read once — scan_lazy_kernel
+    uint32_t stream_once;       // the launch has ONE query block (every store byte it touches is read once), or its filter
+                                // plane is too big for the Infinity Cache to keep between two query blocks: scan_lazy_kernel
                                 // then loads its filter words with the non-temporal hint (no cache line is kept for a
                                 // re-read that never comes): 66.7 -> 60.6 us per pass over the 50M store's 400 MB plane
                                 // (0.74 -> 0.82 of 8 TB/s), 14.0 -> 13.1 us on the 10M store (profiles/r03_stream_nt.txt)

@@ -75,6 +75,17 @@ def main():
         store.scan_each(qs, D, hits.data_ptr(), cap, counts.data_ptr(), True)  # capture
         torch.cuda.synchronize()
         res["scan_each_graph"] = timed(lambda: store.scan_each(qs, D, hits.data_ptr(), cap, counts.data_ptr(), True))
+        if zone == 0:
+            # the same K passes as ONE launch: query blocks of one query (smafa_set_query_block 1) — the grid walks the query
+            # list, workgroup after workgroup, with no kernel boundary between two passes (rows of all queries in one list)
+            big = torch.zeros(K * cap * 3, dtype=torch.int32, device=dev)
+            total = torch.zeros(1, dtype=torch.int64, device=dev)
+            store.set_query_block(1)
+            res["one_launch_blocks_of_one"] = timed(lambda: store.scan_launch(qs, D, None, big.data_ptr(), K * cap, total.data_ptr()))
+            res["one_launch_blocks_of_one"]["kernel"] = store.last_scan_kernel()
+            res["one_launch_blocks_of_one"]["query_blocks"] = store.last_scan_plan()["query_blocks"]
+            res["one_launch_blocks_of_one"]["rows"] = int(total.item())
+            store.set_query_block(0)
         k_ms = []
         for i in range(20):
             store.scan_launch(ones[i % 8], D, None, hits.data_ptr(), cap, counts.data_ptr())
@@ -84,7 +95,7 @@ def main():
         plane = info.hbm_bytes * (info.words_per_plane * 4) / info.bytes_per_subject
         res["filter_plane_bytes"] = plane
         if zone == 0:
-            for k in ("python_loop_scan_launch", "scan_each", "scan_each_graph"):
+            for k in ("python_loop_scan_launch", "scan_each", "scan_each_graph", "one_launch_blocks_of_one"):
                 res[k]["frac_of_8TBs"] = plane / res[k]["wall_ms_per_pass"] / 1e6 / 8000.0
             res["kernel_frac_of_8TBs"] = plane / res["kernel_ms_median"] / 1e6 / 8000.0
         out["zone_level_%d" % zone] = res
