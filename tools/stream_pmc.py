@@ -19,6 +19,9 @@ for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recurs
 res = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 tools/stream_probe.py --db-rows 50000000 --passes 60", "rc": rc}
 for kernel in ("scan_lazy_kernel<5, 5, 2, 4, false>", "scan_zone_few_kernel<5, 5, 2>"):
     mine = [r for r in rows if kernel in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+    # one-query passes only: the probe also runs the same 200 queries as ONE launch (200 query blocks, 200 x the bytes)
+    one_pass_grid = min((int(r["Grid_Size"]) for r in mine), default=0)
+    mine = [r for r in mine if int(r["Grid_Size"]) == one_pass_grid]
     if not mine:
         continue
     fetch = [float(r["Counter_Value"]) * 1024.0 * 2.0 for r in mine]
