@@ -142,7 +142,7 @@ void smafa_qset_destroy(smafa_qset *qs);
  * receives the number of qualifying rows — exact at any capacity with a fixed bound (max_num_hits absent): it may
  * exceed cap, only the first cap rows to arrive are stored, and a caller can size its buffer from it.  In the
  * tightening modes (max_num_hits = k) a value above cap only says "did not fit".  A fixed-bound scan is ONE kernel
- * launch; nothing has to be reset between calls.  (The first scan after a store has grown by a quarter through many
+ * launch (sets of up to 64 queries: a memset of *d_count in front of it); nothing has to be reset between calls.  (The first scan after a store has grown by a quarter through many
  * appends first sorts it again on the device and waits for that — milliseconds, outside the timed kernel.)
  * max_div / max_num_hits as in smafa_scan_hits, except that rows above kth(query) may remain: rows are kept
  * when dist <= the device's final bound of their query, which is exact for k = 1 and >= kth(query) for k >= 2.
@@ -151,7 +151,8 @@ int smafa_scan_launch(smafa_db *db, smafa_qset *qs, uint32_t max_div, uint32_t m
                       uint64_t cap, void *d_count);
 /* One store pass PER QUERY of a resident set — north_star's literal "each query is broadcast against all subjects" — all
  * enqueued back to back by this one call (no host round trip between passes): query i's rows go to
- * d_hits + i * cap_per_query (rows), its exact count to the i-th uint64 of d_counts.  Each pass is the one-launch
+ * d_hits + i * cap_per_query (rows), its exact count to the i-th uint64 of d_counts (zeroed once for all passes, then each
+ * pass reserves its rows from its own counter).  Each pass is the
  * fixed-bound scan smafa_scan_launch runs for a one-query set; with the zone level off (smafa_set_zone_level 0) it
  * streams the prefilter's whole bit-plane: the HBM-bound form bench.py's `stream` leg times.  use_graph != 0: the passes
  * are captured once as a HIP graph and replayed while the arguments stay the same.  Replaces the same loop as

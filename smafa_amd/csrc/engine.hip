@@ -662,7 +662,7 @@ static uint32_t choose_query_block(const smafa_db *db, uint32_t n_wg_tiles, uint
 // row total to *publish and leaves the counters at zero.
 static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t tile_begin,
                         uint32_t tile_end, uint32_t k_tight, uint32_t thr0, smafa_hit *d_rows, uint64_t rows_cap,
-                        unsigned long long *publish, bool per_query_bounds = false) {
+                        unsigned long long *publish, bool per_query_bounds = false, unsigned long long *own_counter = nullptr) {
     ScanArgs a;
     const bool specialised = db->W <= 4;  // else scan_wide_kernel / scan_generic_kernel
     const bool wide = use_wide(db, thr0);
@@ -696,6 +696,11 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     a.count = db->ctrs.as<unsigned long long>();
     a.done = publish ? reinterpret_cast<uint32_t *>(db->ctrs.as<uint8_t>() + 256) : nullptr;
     a.publish = publish;
+    if (own_counter) {  // the caller zeroed a counter of its own for this launch: rows are reserved from it and it IS the result —
+        a.count = own_counter;  // nobody takes a ticket (smafa_scan_each: a workgroup's returning ticket atomic at the end of
+        a.done = nullptr;       // a one-query pass cost the streaming form 13 % — profiles/r03_stream_nt.txt)
+        a.publish = nullptr;
+    }
     a.order = db->d_order;
     a.zone = db->d_zone;
     a.zone_on = (wide && !zone && !seed && db->W > 4 && zone_pays(db, thr0, true)) ? 1u : 0u;
@@ -740,8 +745,15 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     const uint32_t thr0 = std::min<uint32_t>(max_div, db->L);  // a distance never exceeds seq_len
     const uint32_t n_tiles = (uint32_t)((db->n + kWaveTile - 1) / kWaveTile);
     if (k_tight == 0) {
+        // A handful of queries against a big store is a grid of many short-lived workgroups: there the ticket every workgroup
+        // takes at its end (to find the last one, which publishes the total) costs more than a memset in front of the launch —
+        // the rows are then reserved straight from *d_count (one-query pass over the 50M store: 65 -> 57 us streaming,
+        // 22.4 -> 18.5 us with the zone level; profiles/r03_stream_nt.txt).  Big batches keep the one-launch form.
+        const bool own = nq <= 64u;
+        if (own) HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), db->stream));
         HIP_TRY(hipEventRecord(db->ev0, db->stream));
-        int rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, thr0, d_hits, cap, d_count);
+        int rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, thr0, d_hits, cap, own ? nullptr : d_count, false,
+                              own ? d_count : nullptr);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(db->ev1, db->stream));
         db->timed = true;
@@ -1616,9 +1628,12 @@ int smafa_scan_each(smafa_db *db, smafa_qset *qs, uint32_t max_div, void *d_hits
     const uint32_t thr0 = std::min<uint32_t>(max_div, db->L);
     const uint32_t n_tiles = (uint32_t)((db->n + kWaveTile - 1) / kWaveTile);
     auto enqueue = [&]() -> int {
+        // every pass reserves its rows from its own counter, d_counts[q], zeroed here once for all of them: the count a pass
+        // leaves there is its result, and no workgroup has to find out whether it was the last one
+        HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nq * sizeof(unsigned long long), db->stream));
         for (uint32_t q = 0; q < nq; q++) {
             int r = launch_tiles(db, qs, q, q + 1, 0, n_tiles, 0, thr0, (smafa_hit *)d_hits + (size_t)q * cap_per_query,
-                                 cap_per_query, (unsigned long long *)d_counts + q);
+                                 cap_per_query, nullptr, false, (unsigned long long *)d_counts + q);
             if (r) return r;
         }
         return SMAFA_OK;

@@ -101,6 +101,48 @@ __global__ __launch_bounds__(256) void k_tiles(const uint4 *__restrict__ p, size
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// the same read with pieces of a scan kernel's structure added one by one: MODE 1 = 12 KB of LDS per workgroup (touched),
+// 2 = + three barriers, 3 = + a returning ticket atomic per workgroup (64 counters, as finish_rows), 4 = + 60 VGPRs more per lane
+template <int MODE>
+__global__ __launch_bounds__(256) void k_tiles_plus(const uint4 *__restrict__ p, size_t n_tiles, uint32_t *out, uint32_t *tickets) {
+    __shared__ uint4 lds[MODE >= 1 ? 768 : 1];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const size_t tile0 = ((size_t)blockIdx.x * 4 + wave) * 4;
+    uint32_t acc = 0;
+    uint4 v[8];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const size_t tile = tile0 + t < n_tiles ? tile0 + t : 0;
+        const uint4 *src = p + tile * 640 + 4 * 2 * 64 + lane;
+        v[2 * t] = ld<true>(src);
+        v[2 * t + 1] = ld<true>(src + 64);
+    }
+    if (MODE >= 1) lds[threadIdx.x] = make_uint4(lane, wave, 0u, 0u);
+    if (MODE >= 2) __syncthreads();
+    if (MODE >= 1) acc += lds[(threadIdx.x * 7u) & 255u].x;
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    if (MODE >= 4) {  // register pressure of the real kernel: values that must stay live across the loads
+        uint32_t keep[60];
+#pragma unroll
+        for (int k = 0; k < 60; k++) keep[k] = acc * (k + 3u) + lane;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 60; k++) acc ^= keep[k] >> (k & 7);
+    }
+    if (MODE >= 2) __syncthreads();
+    if (MODE >= 2) __syncthreads();
+    if (MODE >= 3 && threadIdx.x == 0) {
+        uint32_t *mine = tickets + 32 * (1 + blockIdx.x % 64);
+        const uint32_t members = (gridDim.x - blockIdx.x % 64 + 63) / 64;
+        if (atomicAdd(mine, 1u) == members - 1) {
+            atomicExch(mine, 0u);
+            if (atomicAdd(tickets, 1u) == 63u) atomicExch(tickets, 0u);
+        }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 int main() {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
@@ -167,6 +209,35 @@ int main() {
                 printf("%-28s one wave per 4 tiles  %7.2f us/pass  %6.0f GB/s  %.3f of 8 TB/s\n", nt ? "2 KB of every 10 KB, nt" : "2 KB of every 10 KB", ms * 1e3 / 100, gbs, gbs / 8000.0);
             }
         }
+    }
+    {
+        const size_t n_tiles = (50000000 + 255) / 256;
+        uint4 *big = nullptr;
+        uint32_t *tickets = nullptr;
+        CK(hipMalloc(&big, n_tiles * 10240));
+        CK(hipMemset(big, 1, n_tiles * 10240));
+        CK(hipMalloc(&tickets, 65 * 128));
+        CK(hipMemset(tickets, 0, 65 * 128));
+        const int grid = (int)((n_tiles + 15) / 16);
+        auto timeit = [&](const char *name, auto launch) -> int {
+            for (int i = 0; i < 5; i++) launch();
+            CK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < 100; i++) launch();
+            CK(hipEventRecord(e1, nullptr));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double gbs = (double)n_tiles * 2048 * 100 / (ms * 1e-3) / 1e9;
+            printf("%-44s %7.2f us/pass  %6.0f GB/s  %.3f of 8 TB/s\n", name, ms * 1e3 / 100, gbs, gbs / 8000.0);
+            return 0;
+        };
+#define PLUS(name, M) \
+    if (timeit(name, [&] { hipLaunchKernelGGL((k_tiles_plus<M>), dim3(grid), dim3(256), 0, nullptr, big, n_tiles, out, tickets); })) return 1;
+        PLUS("tiles nt, bare", 0)
+        PLUS("tiles nt + 12 KB LDS", 1)
+        PLUS("tiles nt + LDS + 3 barriers", 2)
+        PLUS("tiles nt + LDS + barriers + ticket", 3)
+        PLUS("tiles nt + LDS + barriers + ticket + regs", 4)
     }
     return 0;
 }
