@@ -142,7 +142,7 @@ void smafa_qset_destroy(smafa_qset *qs);
  * receives the number of qualifying rows — exact at any capacity with a fixed bound (max_num_hits absent): it may
  * exceed cap, only the first cap rows to arrive are stored, and a caller can size its buffer from it.  In the
  * tightening modes (max_num_hits = k) a value above cap only says "did not fit".  A fixed-bound scan is ONE kernel
- * launch (sets of up to 64 queries: a memset of *d_count in front of it); nothing has to be reset between calls.  (The first scan after a store has grown by a quarter through many
+ * launch (sets of up to 64 queries: a one-workgroup kernel that zeroes *d_count in front of it); nothing has to be reset between calls.  (The first scan after a store has grown by a quarter through many
  * appends first sorts it again on the device and waits for that — milliseconds, outside the timed kernel.)
  * max_div / max_num_hits as in smafa_scan_hits, except that rows above kth(query) may remain: rows are kept
  * when dist <= the device's final bound of their query, which is exact for k = 1 and >= kth(query) for k >= 2.

@@ -746,11 +746,11 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     const uint32_t n_tiles = (uint32_t)((db->n + kWaveTile - 1) / kWaveTile);
     if (k_tight == 0) {
         // A handful of queries against a big store is a grid of many short-lived workgroups: there the ticket every workgroup
-        // takes at its end (to find the last one, which publishes the total) costs more than a memset in front of the launch —
+        // takes at its end (to find the last one, which publishes the total) costs more than a tiny fill kernel in front of the launch —
         // the rows are then reserved straight from *d_count (one-query pass over the 50M store: 65 -> 57 us streaming,
         // 22.4 -> 18.5 us with the zone level; profiles/r03_stream_nt.txt).  Big batches keep the one-launch form.
         const bool own = nq <= 64u;
-        if (own) HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), db->stream));
+        if (own) hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, db->stream, (uint32_t *)d_count, 0u, (uint64_t)2);
         HIP_TRY(hipEventRecord(db->ev0, db->stream));
         int rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, thr0, d_hits, cap, own ? nullptr : d_count, false,
                               own ? d_count : nullptr);
@@ -1630,7 +1630,10 @@ int smafa_scan_each(smafa_db *db, smafa_qset *qs, uint32_t max_div, void *d_hits
     auto enqueue = [&]() -> int {
         // every pass reserves its rows from its own counter, d_counts[q], zeroed here once for all of them: the count a pass
         // leaves there is its result, and no workgroup has to find out whether it was the last one
-        HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nq * sizeof(unsigned long long), db->stream));
+        // (a kernel, not hipMemsetAsync: the memset node of a captured graph left garbage in the counters when the graph was
+        // replayed — ROCm 7.2; kernel nodes replay as captured)
+        hipLaunchKernelGGL(fill_u32_kernel, dim3((2 * nq + 255) / 256), dim3(256), 0, db->stream, (uint32_t *)d_counts, 0u,
+                           (uint64_t)2 * nq);
         for (uint32_t q = 0; q < nq; q++) {
             int r = launch_tiles(db, qs, q, q + 1, 0, n_tiles, 0, thr0, (smafa_hit *)d_hits + (size_t)q * cap_per_query,
                                  cap_per_query, nullptr, false, (unsigned long long *)d_counts + q);
