@@ -566,11 +566,18 @@ static bool zone_pays(const smafa_db *db, uint32_t thr0, bool prunes) {
 // up to 128 columns: scan_zone_kernel; longer: the zone level inside scan_wide_kernel (ScanArgs::zone_on)
 static bool use_zone(const smafa_db *db, uint32_t thr0, bool prunes) { return db->W <= 4 && zone_pays(db, thr0, prunes); }
 
-static uint32_t tiles_per_wave(const smafa_db *db, bool lazy) {
+static uint32_t tiles_per_wave(const smafa_db *db, bool lazy, uint32_t thr0) {
     if (lazy) return db->W >= 3 ? 2u : 4u;  // every filter word resident: 8 subjects per lane from 3 words on
     if (db->W > 2) return 1;
     if (db->tiles_override == 4) return db->P == 2 ? 4u : 2u;
     if (db->tiles_override == 1 || db->tiles_override == 2) return db->tiles_override;
+    // Two tiles per wave share the per-query work of the bound levels between 8 subjects per lane — which pays while those
+    // levels reject most pairs.  Where (nearly) every pair gets the full comparison — prefilter off, or a bound above 16 with
+    // four and more planes (FOLD 2 / 3) — one tile per wave is faster: 80 registers less, more waves resident, and for a one-query
+    // pass shorter waves that keep the memory pipeline full.  10 000 x 10M aa: prefilter off 30.5 -> 25.4 ms, bound 24
+    // 15.0 -> 14.4 ms, best hit without a bound 23.1 -> 21.8 ms, bound 8 the other way (8.3 -> 9.6 ms: stays at two); one query
+    // streaming every plane of the 10M store: 70.3 -> 58.4 us = 0.72 -> 0.86 of HBM peak (profiles/r03_stream_nt.txt).
+    if (db->P >= 4 && (!db->use_filter || thr0 > 16u)) return 1u;
     return 2u;
 }
 
@@ -673,7 +680,7 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     const bool zone = specialised && !seed && use_zone(db, thr0, prefilter_prunes(db, thr0));
     lazy = lazy || zone;  // (the plan reported by smafa_last_scan_plan: a filter-plane-resident kernel)
     const uint32_t T = zone ? (q_end - q_begin <= 64u ? (uint32_t)kFewTiles : (uint32_t)kZoneTiles)
-                     : wide ? (uint32_t)kWideTiles : specialised ? tiles_per_wave(db, lazy) : (uint32_t)kGenericTiles;
+                     : wide ? (uint32_t)kWideTiles : specialised ? tiles_per_wave(db, lazy, thr0) : (uint32_t)kGenericTiles;
     a.tile_begin = tile_begin;
     a.tile_end = tile_end;
     const uint32_t wg_waves = (zone && q_end - q_begin > 64u) ? (uint32_t)kZoneWgWaves : (uint32_t)kWgWaves;
@@ -705,10 +712,11 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     a.zone = db->d_zone;
     a.zone_on = (wide && !zone && !seed && db->W > 4 && zone_pays(db, thr0, true)) ? 1u : 0u;
     const uint64_t n_qblocks = (q_end - q_begin + a.qb_size - 1) / a.qb_size;
-    // non-temporal filter loads (scan_lazy_kernel): where a cached copy is never read again — one query block, or a filter
-    // plane of the range too big for the 256 MiB Infinity Cache to hold until the next query block comes round
-    const uint64_t range_filter_bytes = (uint64_t)(tile_end - tile_begin) * db->W * 1024u;
-    a.stream_once = (db->stream_nt && (n_qblocks == 1 || range_filter_bytes >= (256ull << 20))) ? 1u : 0u;
+    // non-temporal loads (scan_lazy_kernel's filter words, scan_kernel's tiles): where a cached copy is never read again — one
+    // query block, or more bytes per query block than the 256 MiB Infinity Cache holds until the next one comes round
+    // (bytes one query block reads: the filter plane's words for the filter-plane-resident kernels, whole tiles for scan_kernel)
+    const uint64_t range_bytes = (uint64_t)(tile_end - tile_begin) * (lazy ? db->W : db->P * db->W) * 1024u;
+    a.stream_once = (db->stream_nt && (n_qblocks == 1 || range_bytes >= (256ull << 20))) ? 1u : 0u;
     const uint64_t grid = n_qblocks * a.n_wg_tiles;
     if (grid > 0x7fffffffull)
         return set_error(SMAFA_ERR_INVALID, "scan grid too large (%llu workgroups)", (unsigned long long)grid);

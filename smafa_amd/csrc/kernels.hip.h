@@ -119,9 +119,9 @@ struct ScanArgs {
     const uint4 *zone;          // per wave tile: {bits all its subjects share in filter word 0, which bits those are,
                                 //                 the same for word 1} — see zone_kernel
     uint32_t zone_on;           // scan_wide_kernel: apply the zone level (the store is sorted well enough for it to pay)
-    uint32_t stream_once;       // the launch has ONE query block (every store byte it touches is read once), or its filter
-                                // plane is too big for the Infinity Cache to keep between two query blocks: scan_lazy_kernel
-                                // then loads its filter words with the non-temporal hint (no cache line is kept for a
+    uint32_t stream_once;       // the launch has ONE query block (every store byte it touches is read once), or what a query
+                                // block reads is too big for the Infinity Cache to keep until the next one: scan_lazy_kernel
+                                // then loads its filter words (scan_kernel: its tiles) with the non-temporal hint (no cache line is kept for a
                                 // re-read that never comes): 66.7 -> 60.6 us per pass over the 50M store's 400 MB plane
                                 // (0.74 -> 0.82 of 8 TB/s), 14.0 -> 13.1 us on the 10M store (profiles/r03_stream_nt.txt)
 };
@@ -314,8 +314,13 @@ __global__ __launch_bounds__(256, scan_min_waves(PS, W, T)) void scan_kernel(con
     for (int t = 0; t < T; t++) {
         const bool live = tile0 + t < a.tile_end;
         const uint4 *src = planes + (size_t)(live ? tile0 + t : a.tile_begin) * (PS * W * 64) + lane;
+        if (a.stream_once) {  // bytes this launch reads once (or that no cache can hold until the next query block)
 #pragma unroll
-        for (int i = 0; i < PS * W; i++) s[t][i] = src[i * 64];
+            for (int i = 0; i < PS * W; i++) s[t][i] = ld_nt(src + i * 64);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PS * W; i++) s[t][i] = src[i * 64];
+        }
     }
     const bool active = tile0 < a.tile_end;
     const uint32_t q0 = a.q_begin + qblock * a.qb_size;
