@@ -577,7 +577,8 @@ static uint32_t tiles_per_wave(const smafa_db *db, bool lazy, uint32_t thr0) {
     // pass shorter waves that keep the memory pipeline full.  10 000 x 10M aa: prefilter off 30.5 -> 25.4 ms, bound 24
     // 15.0 -> 14.4 ms, best hit without a bound 23.1 -> 21.8 ms, bound 8 the other way (8.3 -> 9.6 ms: stays at two); one query
     // streaming every plane of the 10M store: 70.3 -> 58.4 us = 0.72 -> 0.86 of HBM peak (profiles/r03_stream_nt.txt).
-    if (db->P >= 4 && (!db->use_filter || thr0 > 16u)) return 1u;
+    // (nucleotide stores the same way, less to gain: best hit without a bound, half the queries unrelated, 13.6 -> 12.8 ms)
+    if (!db->use_filter || thr0 > 16u) return 1u;
     return 2u;
 }
 
@@ -731,7 +732,8 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
 
 // Scan queries [q_begin, q_end) of a resident set against the whole store; rows and their count stay on
 // the device.
-// k_tight = 0: ONE launch, fixed bound max_div: the kernel appends straight into the caller's list and its last
+// k_tight = 0: ONE launch (up to 64 queries: a one-workgroup kernel zeroes *d_count first and nobody takes a ticket), fixed
+// bound max_div: the kernel appends straight into the caller's list and — big batches — its last
 // workgroup publishes the total in *d_count (which may exceed cap: the rows past it are dropped, the count is exact).
 // k_tight >= 1: the bound of each query is lowered to its running k-th smallest distance while the scan proceeds.
 // Workgroups of one launch run side by side and would all start from the loose initial bound, so the store is walked
