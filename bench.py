@@ -49,7 +49,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz (one wave64 VALU op = 2 cycles)
-PMC_JSONS = [os.path.join(ROOT, "profiles", "r03_pmc.json"), os.path.join(ROOT, "profiles", "r02_pmc.json")]
+PMC_JSONS = [os.path.join(ROOT, "profiles", "r%02d_pmc.json" % r) for r in (4, 3, 2)]  # first file with a matching record wins
+STREAM_PMC_JSONS = [os.path.join(ROOT, "profiles", "r%02d_stream_pmc.json" % r) for r in (4, 3)]
 T_START = time.time()
 
 
@@ -68,10 +69,14 @@ def parse_args(argv=None):
     ap.add_argument("--store", choices=["uniform", "related"], default="uniform",
                     help="related: the TIMED workload is the related-families store (default: uniform letters; the related "
                          "store is then a side leg)")
-    ap.add_argument("--mode", choices=["scan", "besthit"], default="scan",
+    ap.add_argument("--mode", choices=["scan", "besthit", "kth"], default="scan",
                     help="besthit: the TIMED step is smafa_scan_hits with max_num_hits = 1 and no bound (`smafa query` "
-                         "without --max-divergence); --far-frac of the queries are uniform random (no near subject)")
+                         "without --max-divergence); --far-frac of the queries are uniform random (no near subject).  "
+                         "kth: the TIMED step is smafa_scan_hits with max_num_hits = --kth-k (the K branch, src/lib.rs:242-295) "
+                         "on the planted queries, without a bound unless --kth-bounded")
     ap.add_argument("--far-frac", type=float, default=0.5)
+    ap.add_argument("--kth-k", type=int, default=5, help="--mode kth: max_num_hits")
+    ap.add_argument("--kth-bounded", action="store_true", help="--mode kth: also pass --max-div as max_divergence")
     ap.add_argument("--prefilter", type=int, choices=[0, 1], default=1, help="0: the TIMED launches run with the prefilter off")
     ap.add_argument("--query-block", type=int, default=0, help="queries per workgroup pass (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,6 +92,12 @@ def parse_args(argv=None):
     ap.add_argument("--collective", choices=["gather", "all_gather"], default="gather",
                     help="how the per-rank row lists reach rank 0 each step (N > 1)")
     ap.add_argument("--single-device", action="store_true", help="testing only: every rank uses GPU 0")
+    ap.add_argument("--full-record", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
+                    help="where the full record (every leg in detail, ~30 KB) is written; stdout carries the compact line only")
+    ap.add_argument("--configs-scale", type=float, default=1.0,
+                    help="testing only: the BASELINE configs block with every size multiplied by this (and run whatever the timed "
+                         "workload is), so that the line's length can be checked with every leg present")
+    ap.add_argument("--no-kth", action="store_true", help="skip the k-th-mode leg (--max-num-hits 5 / 50)")
     return ap.parse_args(argv)
 
 
@@ -160,7 +171,8 @@ def pmc_lookup(cfg: dict, kernel: str):
     def norm(c):
         return (c.get("db_rows"), c.get("seq_len"), c.get("queries"), c.get("max_div"), c.get("alphabet"),
                 c.get("store", "uniform"), float(c.get("n_frac", 0.0)), int(c.get("prefilter", 1)), c.get("mode", "scan"),
-                float(c.get("far_frac", 0.5)) if c.get("mode", "scan") == "besthit" else 0.0)
+                float(c.get("far_frac", 0.5)) if c.get("mode", "scan") == "besthit" else 0.0,
+                (int(c.get("kth_k", 0)), bool(c.get("kth_bounded", False))) if c.get("mode", "scan") == "kth" else (0, False))
     for rec in pmc_records():
         if norm(rec.get("config", {})) == norm(cfg) and rec.get("kernel") == kernel.split(" (")[0]:
             return rec
@@ -242,6 +254,18 @@ def cpu_baselines(N, L, D, alphabet_name, subj_codes, q_codes, budget_s):
         dt = time.perf_counter() - t
         out[key] = {"value": n_s / dt, "unit": "query seqs/s", "cores": 1, "queries": n_s,
                     "build": "gcc -O3 -march=native" if native else "gcc -O3, baseline x86-64 (no POPCNT)"}
+        if not native:
+            # the K branch (src/lib.rs:242-295): per query an N x 16 B tuple vector and a full sort of it, on top of the distances
+            t = time.perf_counter()
+            db.bench_kmode(enc[:1], oracle.NO_LIMIT, 5)
+            n_k = sample_size(time.perf_counter() - t, 64)
+            t = time.perf_counter()
+            db.bench_kmode(enc[:n_k], oracle.NO_LIMIT, 5)
+            dtk = time.perf_counter() - t
+            out["kmode"] = {"value": n_k / dtk, "unit": "query seqs/s", "cores": 1, "queries": n_k, "max_num_hits": 5,
+                            "sample": "first %d queries of the B1 batch, max_num_hits 5, no bound: oracle C port of src/lib.rs:238 + "
+                                      ":243-250 (tuple vector + full merge sort per query) + :253-293, gcc -O3 without POPCNT, 1 thread"
+                                      % n_k}
         if native:
             workers = min(16, os.cpu_count() or 1)
             per_q = dt / n_s
@@ -276,6 +300,132 @@ def cpu_baselines(N, L, D, alphabet_name, subj_codes, q_codes, budget_s):
         out["aa_code_bytes"] = {"value": n_s / dt, "unit": "query seqs/s", "cores": 1, "queries": n_s,
                                 "build": "gcc -O3, one byte per column, the same store and queries as the GPU"}
     return out
+
+
+# ------------------------------------------------------------------------------------------ the line on stdout
+LINE_LIMIT = 4096  # the driver keeps a tail of stdout: the ONE line it parses must fit it with room to spare
+
+
+def sig(x, n=4):
+    """numbers to n significant digits (the line is read by a parser and a judge, not by a plotter)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float("%.*g" % (n, float(x)))
+    except (TypeError, ValueError):
+        return None
+
+
+def compact_line(full: dict, full_path=None) -> dict:
+    """The one JSON line of stdout, <= LINE_LIMIT characters: the contract's fields, the headline roofline (+ the HBM-bound
+    one-query pass as roofline.hbm_stream), cpu_baseline, and one short array per side leg.  Every detail (notes, sources,
+    per-leg roofline blocks) stays in the full record (`full_record`)."""
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    cfg = dict(full.get("config") or {})
+    cfg["workload"] = str(cfg.get("workload", ""))[:200]
+    cfg.pop("far_frac", None) if cfg.get("mode") != "besthit" else None
+    cfg["parallelism"] = str(cfg.get("parallelism", ""))[:80]
+    r = full.get("roofline") or {}
+    roof = {"bound": r.get("bound"), "kernel": r.get("kernel"), "achieved": sig(r.get("achieved")), "peak": sig(r.get("peak"), 6),
+            "unit": r.get("unit"), "frac": sig(r.get("frac")), "kernel_ms_avg": sig(r.get("kernel_ms_avg")),
+            "traffic": sig(r.get("traffic")), "hbm_frac": sig(r.get("hbm_frac_from_recorded_traffic")),
+            "valu_per_1024_pairs": sig(r.get("valu_insts_per_1024_pairs")),
+            "algorithmic_bytes": r.get("algorithmic_bytes_per_launch"), "algorithmic_reuse_x": sig(r.get("algorithmic_reuse_x")),
+            "insts_source_is_this_build": r.get("insts_source_is_this_build")}
+    st = full.get("stream") or {}
+    best = st.get("hbm_store") or st.get("metric_store")
+    if best:
+        sr = st.get("roofline") or {}
+        roof["hbm_stream"] = {
+            "store": best.get("store"), "bytes_per_pass": best.get("streamed_bytes_per_pass"),
+            "served_by": "hbm" if (best.get("streamed_bytes_per_pass") or 0) > (256 << 20) else "cache",
+            "us_wall": sig(1e3 * (g(best, "streaming", "ms_per_query_wall") or 0)),
+            "us_kernel": sig(1e3 * (g(best, "streaming", "kernel_ms_median") or 0)),
+            "frac_wall": sig(g(best, "streaming", "frac_wall_streamed")), "frac_kernel": sig(g(best, "streaming", "frac_kernel_streamed")),
+            "fetched_over_plane": sig(st.get("fetched_over_plane"), 5),
+            "every_plane_metric_store": [sig(1e3 * (g(st, "metric_store", "streaming_every_plane", "ms_per_query_wall") or 0)),
+                                         sig(g(st, "metric_store", "streaming_every_plane", "frac_wall_streamed"))],
+            "read_ceiling_frac": sig(st.get("empirical_read_ceiling_frac_of_peak")), "rows_identical": best.get("rows_identical"),
+            "peak": sr.get("peak"), "unit": sr.get("unit")}
+    c = full.get("cpu_baseline")
+    cpu = None
+    if c:
+        cpu = {"value": sig(c.get("value")), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"),
+               "sample": str(c.get("sample", ""))[:160], "cpu_model": c.get("cpu_model"),
+               "b1n": sig(g(c, "b1n", "value")), "b2": [sig(g(c, "b2", "value")), g(c, "b2", "cores")],
+               "aa_code_bytes": sig(g(c, "aa_code_bytes", "value"))}
+        if c.get("kmode"):
+            cpu["kmode"] = {k: sig(v) if not isinstance(v, (str, list)) else v for k, v in c["kmode"].items() if k != "sample"}
+    legs = {}
+    u = full.get("unfiltered")
+    if u:
+        legs["unfiltered"] = [sig(u.get("kernel_ms")), sig(g(u, "roofline", "frac"))]
+    for b in full.get("loose_bounds") or []:
+        legs["bound%d" % b.get("max_divergence", 0)] = [sig(b.get("kernel_ms")), sig(g(b, "roofline", "frac")), b.get("verified")]
+    bh = full.get("besthit_unbounded")
+    if bh:
+        legs["besthit_mixed"] = [sig(bh.get("wall_ms")), sig(bh.get("queries_per_s_wall")), sig(g(bh, "roofline", "frac")), bh.get("verified")]
+        legs["besthit_far"] = [sig(g(bh, "far_queries_only", "wall_ms")), sig(g(bh, "far_queries_only", "queries_per_s_wall"))]
+    rel = full.get("related")
+    if rel:
+        legs["related"] = [sig(rel.get("kernel_ms")), sig(rel.get("queries_per_s")), sig(g(rel, "roofline", "frac")), rel.get("verified")]
+        nm = rel.get("besthit_novel_members")
+        if nm:
+            legs["besthit_novel"] = [sig(nm.get("wall_ms")), sig(nm.get("queries_per_s_wall")), None, nm.get("verified")]
+    for name, leg in (full.get("kth") or {}).items():
+        if isinstance(leg, dict):
+            legs[name] = [sig(leg.get("wall_ms")), sig(leg.get("queries_per_s_wall")), sig(g(leg, "roofline", "frac")),
+                          leg.get("verified"), sig(leg.get("kernel_ms"))]
+    ha = full.get("host_api")
+    if ha:
+        legs["host_api"] = [sig(ha.get("ms_per_batch")), sig(ha.get("queries_per_s")), None, ha.get("rows_identical_to_device_launch")]
+    short = {"configs[1] 1M aa": "cfg1", "configs[2] 10M nt, N-free (2-bit store)": "cfg2",
+             "configs[2] 10M nt, 0.1 % N (3-plane store)": "cfg2N",
+             "configs[3] one rank's share: 50M aa x 125k of 1M queries": "cfg3", "configs[4] cluster 5M aa": "cfg4"}
+    for name, leg in (full.get("configs") or {}).items():
+        key = short.get(name, name[:12])
+        if "wall_s" in leg:  # cluster: seconds, records/s
+            legs[key] = [sig(leg.get("wall_s")), sig(leg.get("records_per_s")), sig(g(leg, "roofline", "frac")), leg.get("verified"),
+                         sig(g(leg, "stages", "scan_kernels_ms")), sig(g(leg, "cpu_baseline", "extrapolated_full_run_s"))]
+        else:
+            legs[key] = [sig(leg.get("kernel_ms")), sig(leg.get("queries_per_s")), sig(g(leg, "roofline", "frac")), leg.get("verified")]
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = sig(out["value"], 7), sig(out["ms_per_step"], 6)
+    out.update({"config": cfg, "residues_per_s": sig(full.get("residues_per_s")), "rows_per_step": full.get("rows_per_step"),
+                "verified": full.get("verified"), "build_id": full.get("build_id"), "roofline": roof, "cpu_baseline": cpu,
+                "legs": legs,
+                "legs_key": "[ms (kernel; wall for besthit*/kth*/host_api; cfg4: wall s), query seqs/s (cfg4: records/s), "
+                            "roofline frac, verified, ..]; unfiltered/boundN: [kernel ms, frac, verified]; kth*: 5th = kernel ms; "
+                            "cfg4: 5th = scan kernel ms, 6th = CPU s extrapolated by pairs from a prefix",
+                "gathered_bytes_per_rank_per_step": full.get("gathered_bytes_per_rank_per_step"),
+                "run_s": full.get("run_s"), "skipped_for_time": [s_.get("leg") for s_ in full.get("skipped_for_time") or []],
+                "full_record": full_path})
+    # the limit is a contract: shed the least important blocks rather than overrun it
+    for drop in ("legs_key", "skipped_for_time", "residues_per_s", "legs"):
+        if len(json.dumps(out)) <= LINE_LIMIT:
+            break
+        out.pop(drop, None)
+    return out
+
+
+def emit(full: dict, full_path) -> None:
+    """full record -> file (best effort), compact line -> the LAST line of stdout"""
+    written = None
+    if full_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(full_path)), exist_ok=True)
+            with open(full_path, "w") as f:
+                json.dump(full, f)
+                f.write("\n")
+            written = os.path.relpath(full_path, ROOT) if os.path.abspath(full_path).startswith(ROOT) else full_path
+        except OSError as e:
+            print("bench.py: full record not written (%s)" % e, file=sys.stderr)
+    line = json.dumps(compact_line(full, written))
+    assert len(line) <= LINE_LIMIT, len(line)
+    sys.stdout.flush()
+    print(line, flush=True)
+
 
 
 # ------------------------------------------------------------------------------------------ helpers for the side legs
@@ -344,6 +494,48 @@ def oracle_sample(np, subj, qry, rows, D, pick):
     return sorted_rows(got).tobytes() == want_a.tobytes()
 
 
+def expected_with_k(np, d, k, bound):
+    """rows (subject, dist) the reference prints for ONE query given all its N distances (src/lib.rs:242-313): k = 1 or None:
+    every subject at the minimum; k >= 2: every subject within the k-th smallest distance (all of them when k > N), both
+    capped by `bound` (max_divergence) when there is one; in (dist, subject) order"""
+    if not k or k == 1:
+        thr = int(d.min())
+    else:
+        thr = int(np.partition(d, k - 1)[k - 1]) if k <= len(d) else int(d.max())
+    if bound is not None and (not k or k == 1) and thr > bound:
+        return np.zeros((0, 2), dtype=np.uint32)
+    if bound is not None:
+        thr = min(thr, int(bound))
+    idx = np.nonzero(d <= thr)[0]
+    idx = idx[np.argsort(d[idx], kind="stable")]
+    return np.stack([idx, d[idx]], axis=1).astype(np.uint32)
+
+
+def kth_rows_ok(np, subj, qry, rows, k, bound, pick):
+    """a k-th-mode row list (n, 3) [query, subject, dist] ordered (query, dist, subject): every distance recomputed from the
+    code bytes; per query the k-th rule's own invariant (fewer than k rows strictly below the largest reported distance, and
+    without a bound at least min(k, N) rows); the sampled queries' complete lists against the oracle's distances"""
+    import oracle
+
+    rec = (subj[rows[:, 1]] != qry[rows[:, 0]]).sum(axis=1)
+    ok = bool((rec == rows[:, 2]).all())
+    Q = len(qry)
+    n_rows = np.bincount(rows[:, 0], minlength=Q)
+    last = np.zeros(Q, dtype=np.int64)
+    np.maximum.at(last, rows[:, 0], rows[:, 2])
+    below = np.bincount(rows[:, 0], weights=(rows[:, 2] < last[rows[:, 0]]), minlength=Q)
+    ok = ok and bool((below < max(k, 1)).all())
+    if bound is None:
+        ok = ok and bool((n_rows >= min(max(k, 1), len(subj))).all())
+    else:
+        ok = ok and bool((rows[:, 2] <= bound).all())
+    for qi in pick:
+        want = expected_with_k(np, oracle.distances_codes(subj, qry[qi]), k, bound)
+        mine = rows[rows[:, 0] == qi][:, 1:]
+        ok = ok and mine.tobytes() == want.tobytes()
+    return ok
+
+
 def main() -> int:
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -362,8 +554,11 @@ def main() -> int:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available() or smafa_amd.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the scan engine has no CPU fallback")
-    if args.mode == "besthit" and world > 1:
-        raise SystemExit("--mode besthit is a one-GPU leg")
+    if args.mode != "scan" and world > 1:
+        raise SystemExit("--mode %s is a one-GPU leg" % args.mode)
+    call_mode = args.mode != "scan"  # the TIMED step is one host-buffer call (smafa_scan_hits), not one device launch
+    call_k = 1 if args.mode == "besthit" else args.kth_k
+    call_bound = args.max_div if (args.mode == "kth" and args.kth_bounded) else None
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -451,8 +646,8 @@ def main() -> int:
             stream.wait_event(gather_done[b])  # the gather that read this buffer two steps ago has finished
         if i_timed is not None:
             ev[i_timed][0].record(stream)
-        if args.mode == "besthit":
-            step.rows = store.scan(my_q, max_divergence=None, max_num_hits=1)
+        if call_mode:
+            step.rows = store.scan(my_q, max_divergence=call_bound, max_num_hits=call_k)
             besthit_stats.append(store.last_call_stats())
         else:
             store.scan_launch(qset, D, None, bufs[b].data_ptr() + 4 * HEAD, cap, bufs[b].data_ptr())
@@ -502,7 +697,7 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_s = float(t.item())
 
-    if args.mode == "besthit":
+    if call_mode:
         kernel_ms = [s["kernel_ms"] for s in besthit_stats[args.warmup:]]
         wall_ms = [a.elapsed_time(b) for a, b in ev]
     else:
@@ -512,13 +707,23 @@ def main() -> int:
     plan = store.last_scan_plan()  # which kernel form the timed launches used
     kernel_name = store.last_scan_kernel()
     cfg = {"db_rows": N, "seq_len": L, "queries": Q, "max_div": D, "alphabet": args.alphabet, "store": args.store,
-           "n_frac": args.n_frac, "prefilter": args.prefilter, "mode": args.mode, "far_frac": args.far_frac}
+           "n_frac": args.n_frac, "prefilter": args.prefilter, "mode": args.mode, "far_frac": args.far_frac,
+           "kth_k": args.kth_k, "kth_bounded": bool(args.kth_bounded)}
 
     B = Bench(torch, dev, stream, local_rank, cap)
 
     # ---- result checks (outside the timed region)
     checks = {}
-    if args.mode == "besthit":
+    if args.mode == "kth":
+        rows = rows3(step.rows)
+        n_rows = len(rows)
+        if rank == 0:
+            import oracle
+
+            oracle.build()
+        checks["kth_rows_ok_incl_oracle_sample"] = kth_rows_ok(np, subj, my_q, rows, call_k, call_bound, np.array([0, Q // 2, Q - 1]))
+        checks["oracle_sample_queries"] = 3
+    elif args.mode == "besthit":
         rows = rows3(step.rows)
         n_rows = len(rows)
         rec = (subj[rows[:, 1]] != my_q[rows[:, 0]]).sum(axis=1)
@@ -665,6 +870,36 @@ def main() -> int:
                            "(seed 9): their nearest subject is ~45 columns away, every lower bound passes, every pair "
                            "gets the full comparison"}
         ok = ok and bool(v)
+
+    # ---- the K branch (`smafa query --max-num-hits k`, k >= 2: src/lib.rs:242-295 — the reference's most expensive mode: an
+    #      N x 16 B tuple vector and a full sort per query): the planted queries with k = 5 and 50, without a bound and with
+    #      --max-divergence D.  Without a bound every query's k-th nearest subject is ~40 columns away on this store (uniform
+    #      letters: one planted neighbour, the rest unrelated), i.e. the loose-bound path: count first, append second.
+    kth = None
+    if side_legs and args.mode == "scan" and args.store == "uniform" and not args.no_kth and in_budget("kth", 12):
+        kth = {"note": "smafa_scan_hits(max_num_hits = k[, max_divergence]) on the %d planted queries: host code bytes in, ordered rows "
+                       "out; kernel_ms = all scan kernels of the call; verified = every distance recomputed, the k-th rule's "
+                       "invariants for every query, complete lists of 3 sampled queries == oracle distances + the rule" % Q}
+        for k in (5, 50):
+            for bound in (None, D):
+                name = "kth%d" % k + ("_d%d" % bound if bound is not None else "")
+                store.scan(my_q[:256], max_divergence=bound, max_num_hits=k)
+                walls, kms, st = [], [], None
+                for _ in range(3):
+                    tq = time.perf_counter()
+                    r_k = store.scan(my_q, max_divergence=bound, max_num_hits=k)
+                    walls.append((time.perf_counter() - tq) * 1e3)
+                    st = store.last_call_stats()
+                    kms.append(st["kernel_ms"])
+                rk = rows3(r_k)
+                v = kth_rows_ok(np, subj, my_q, rk, k, bound, np.array([1, Q // 3, Q - 2]))
+                k_med, w_med = float(np.median(kms)), float(np.median(walls))
+                kth[name] = {"max_num_hits": k, "max_divergence": bound, "queries": Q, "wall_ms": w_med, "kernel_ms": k_med,
+                             "queries_per_s_wall": Q / (w_med * 1e-3), "queries_per_s_kernel": Q / (k_med * 1e-3) if k_med else None,
+                             "scans": st["scans"], "launches": st["launches"], "rows": int(len(rk)), "verified": bool(v),
+                             "roofline": roofline_block(dict(cfg, mode="kth", kth_k=k, kth_bounded=bound is not None),
+                                                        "scan kernels of one call", k_med, Q * N, alg_bytes_main, build_id)}
+                ok = ok and bool(v)
 
     # ---- stream mode: ONE query per pass — the HBM-bound form (north_star's literal "broadcast each query against
     #      all subjects"); three fractions of the 8 TB/s peak + the box's empirical read ceiling.
@@ -832,7 +1067,7 @@ def main() -> int:
                       "(equality pass), gcc -O3 without POPCNT (cargo's release default), 1 thread — the reference is "
                       "single-threaded" % (b["b1"]["queries"], 512, L, N),
             "cpu_model": b["cpu_model"], "host_cores_available": b["nproc"],
-            "b1": b["b1"], "b1n": b["b1n"], "b2": b["b2"],
+            "b1": b["b1"], "b1n": b["b1n"], "b2": b["b2"], "kmode": b.get("kmode"),
         }
         if "aa_code_bytes" in b:
             cpu["aa_code_bytes"] = b["aa_code_bytes"]
@@ -910,12 +1145,14 @@ def main() -> int:
     # ---- BASELINE.json configs[1..4], each verified, each with kernel and wall time (N = 1: configs[3] = one rank's share)
     configs = None
     if side_legs and args.mode == "scan" and not args.no_configs and args.store == "uniform" and args.alphabet == "aa" \
-            and (N, Q, D) == (10_000_000, 10_000, 5):
+            and ((N, Q, D) == (10_000_000, 10_000, 5) or args.configs_scale != 1.0):
         configs = {}
+        cs = args.configs_scale
 
         def query_config(name, n, q, alpha, d, n_frac=0.0, stream_too=False, need_s=20):
             if not in_budget(name, need_s):
                 return
+            n, q = max(int(n * cs), 4096), max(int(q * cs), 256)
             a_name = "aa" if alpha else "nt"
             tg = time.time()
             s_c = synth.subjects(n, L, alpha, seed=1 if alpha else 2, n_frac=n_frac)
@@ -972,10 +1209,23 @@ def main() -> int:
 
         # configs[4]: `smafa cluster` (src/cluster.rs:13-94) on 5M x 60 aa records through the product CLI
         if in_budget("configs[4] cluster", 60):
-            configs["configs[4] cluster 5M aa"] = cluster_config(np, synth, args, build_id)
+            configs["configs[4] cluster 5M aa"] = cluster_config(np, synth, args, build_id, max(int(100_000 * cs), 200))
             ok = ok and configs["configs[4] cluster 5M aa"]["verified"]
 
     if stream_info is not None:
+        # HBM bytes per streaming pass from the hardware counter (rocprofv3 --pmc FETCH_SIZE around tools/stream_probe.py on the
+        # 50M store, tools/stream_pmc.py): the committed record, not measured in this run
+        for path in STREAM_PMC_JSONS:
+            if os.path.exists(path):
+                rec = json.load(open(path))
+                for kname, r in rec.items():
+                    if isinstance(r, dict) and "scan_lazy_kernel" in kname:
+                        stream_info["fetched_over_plane"] = r.get("fetched_over_plane")
+                        stream_info["counters"] = {"source": os.path.relpath(path, ROOT), "kernel": kname, "build_id": rec.get("build_id"),
+                                                   "hbm_bytes_per_pass": r.get("hbm_bytes_per_pass_avg"),
+                                                   "kernel_us_median_under_profiler": r.get("kernel_us_median"),
+                                                   "frac_of_peak_by_counter_bytes": r.get("frac_of_8TBs")}
+                break
         # the box's empirical read ceiling: a trivial sum over 8 GiB
         ceiling = smafa_amd.hbm_read_probe(local_rank, 8 << 30)
         stream_info["empirical_read_ceiling_GBs"] = ceiling
@@ -1031,10 +1281,12 @@ def main() -> int:
                                     ", N with probability %g per column" % args.n_frac if args.n_frac else ""),
                                 Q, max_subs,
                                 "max-divergence %d" % D if args.mode == "scan" else
+                                "max_num_hits %d (the K branch), %s" % (call_k, "max-divergence %d" % D if args.kth_bounded else "no bound")
+                                if args.mode == "kth" else
                                 "best hit without a bound (max_num_hits 1), %g of the queries uniform random" % args.far_frac)),
                 "db_rows": N, "seq_len": L, "alphabet": args.alphabet, "queries_per_gpu": Q, "max_divergence": D,
                 "store": args.store, "n_frac": args.n_frac, "prefilter": args.prefilter, "mode": args.mode,
-                "far_frac": args.far_frac,
+                "far_frac": args.far_frac, "kth_k": args.kth_k, "kth_bounded": bool(args.kth_bounded),
                 "parallelism": "query shards x%d, DB replicated, RCCL %s of row lists to rank 0" % (world, args.collective),
             },
             "residues_per_s": value * N * L,
@@ -1048,6 +1300,7 @@ def main() -> int:
             "unfiltered": unfiltered,
             "loose_bounds": loose,
             "besthit_unbounded": besthit,
+            "kth": kth,
             "related": related,
             "host_api": host_api,
             "configs": configs,
@@ -1059,13 +1312,13 @@ def main() -> int:
             "run_s": round(elapsed(), 1),
             "skipped_for_time": skipped,
         }
-        print(json.dumps(out), flush=True)
+        emit(out, args.full_record)
     if multi:
         dist.destroy_process_group()
     return 0
 
 
-def cluster_config(np, synth, args, build_id):
+def cluster_config(np, synth, args, build_id, n_roots=100_000):
     """BASELINE configs[4]: `smafa cluster -d 5 --alphabet aa` on 5M x 60 aa records (100k roots x 50 members, 0..4
     substitutions, shuffled, seed 4 — SURVEY 8d) through the product CLI; verified by (i) a 60k-record prefix run that must
     equal the oracle's sequential greedy loop byte for byte and (ii) the full-size properties of the reference's algorithm
@@ -1114,7 +1367,7 @@ def cluster_config(np, synth, args, build_id):
         prefix_ok = r.returncode == 0 and r.stdout == want
         # (ii) the full size
         tg = time.time()
-        recs = synth.cluster_records(100_000, 50, 60, 1, seed=4, max_subs=4)
+        recs = synth.cluster_records(n_roots, 50, 60, 1, seed=4, max_subs=4)
         f_big = os.path.join(tmp, "big.faa")
         write_fasta(f_big, recs)
         tg = time.time() - tg

@@ -78,6 +78,8 @@ def lib(native: bool = False) -> C.CDLL:
     l.orc_bench_besthit_codes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int64]
     l.orc_bench_besthit_onehot.restype = C.c_int64
     l.orc_bench_besthit_onehot.argtypes = [C.POINTER(_WindowSet), C.c_void_p, C.c_size_t, C.c_size_t, C.c_int64]
+    l.orc_bench_kmode_onehot.restype = C.c_int64
+    l.orc_bench_kmode_onehot.argtypes = [C.POINTER(_WindowSet), C.c_void_p, C.c_size_t, C.c_size_t, C.c_int64, C.c_int64]
     l.orc_ws_init.argtypes = [C.POINTER(_WindowSet), C.c_uint32]
     l.orc_ws_push.argtypes = [C.POINTER(_WindowSet), C.c_void_p, C.c_size_t]
     l.orc_ws_free.argtypes = [C.POINTER(_WindowSet)]
@@ -236,6 +238,11 @@ class OnehotDB:
 
     def bench_besthit(self, query_enc: np.ndarray, max_div: int) -> int:
         return self._l.orc_bench_besthit_onehot(C.byref(self._ws), query_enc.ctypes.data, query_enc.shape[0], self.L, max_div)
+
+    def bench_kmode(self, query_enc: np.ndarray, max_div: int, max_num_hits: int) -> int:
+        """rows the K branch (src/lib.rs:242-295) would print; max_div = NO_LIMIT for none"""
+        return self._l.orc_bench_kmode_onehot(C.byref(self._ws), query_enc.ctypes.data, query_enc.shape[0], self.L,
+                                              max_div, max_num_hits)
 
     def close(self):
         self._l.orc_ws_free(C.byref(self._ws))

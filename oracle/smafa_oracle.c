@@ -1074,6 +1074,74 @@ int64_t orc_bench_besthit_onehot(const orc_windowset *ws, const uint64_t *query_
     return rows;
 }
 
+/*
+ * The K branch as the reference runs it (src/lib.rs:242-295), for the cpu_baseline of the k-th modes: per query a fresh
+ * Vec of N (distance, index) tuples (:243-247, 16 bytes each), a full comparison sort of it (:250 — `sort()` on tuples: a
+ * stable merge sort with the lexicographic compare inlined; restated as a top-down merge sort with insertion-sorted runs,
+ * NOT the counting sort orc_select uses for its answers), the k-th tuple's distance (:253-256), and a walk over ALL tuples
+ * that counts the rows that would be printed (:261-293; the reference does not stop at the first tuple beyond the bound).
+ */
+typedef struct {
+    size_t d, i;
+} orc_pair;
+
+static inline int pair_less(const orc_pair *a, const orc_pair *b) { return a->d < b->d || (a->d == b->d && a->i < b->i); }
+
+static void merge_sort_pairs(orc_pair *a, orc_pair *tmp, size_t n) {
+    if (n <= 20) { /* insertion sort of short runs, as the standard library does */
+        for (size_t x = 1; x < n; x++) {
+            orc_pair v = a[x];
+            size_t y = x;
+            while (y > 0 && pair_less(&v, &a[y - 1])) {
+                a[y] = a[y - 1];
+                y--;
+            }
+            a[y] = v;
+        }
+        return;
+    }
+    size_t h = n / 2;
+    merge_sort_pairs(a, tmp, h);
+    merge_sort_pairs(a + h, tmp, n - h);
+    if (!pair_less(&a[h], &a[h - 1])) return; /* already in order */
+    memcpy(tmp, a, h * sizeof(orc_pair));
+    size_t x = 0, y = h, o = 0;
+    while (x < h && y < n) a[o++] = pair_less(&a[y], &tmp[x]) ? a[y++] : tmp[x++];
+    while (x < h) a[o++] = tmp[x++];
+}
+
+int64_t orc_bench_kmode_onehot(const orc_windowset *ws, const uint64_t *query_enc, size_t q, size_t len,
+                               int64_t max_divergence, int64_t max_num_hits) {
+    const size_t n = ws->n;
+    if (n == 0 || max_num_hits < 2) return 0;
+    size_t *distances = (size_t *)malloc(n * sizeof(size_t)); /* :227, allocated once */
+    orc_pair *tmp = (orc_pair *)malloc((n / 2 + 1) * sizeof(orc_pair));
+    int64_t rows = 0;
+    for (size_t qi = 0; qi < q; qi++) {
+        orc_get_distances(ws, query_enc + qi * ws->nw, len, distances); /* :238 */
+        orc_pair *v = (orc_pair *)malloc(n * sizeof(orc_pair));      /* :243-247: collect() allocates per query */
+        for (size_t j = 0; j < n; j++) {
+            v[j].d = distances[j];
+            v[j].i = j;
+        }
+        merge_sort_pairs(v, tmp, n); /* :250 */
+        size_t max_distance;
+        if ((uint64_t)max_num_hits > (uint64_t)n) { /* :253-254 */
+            max_distance = 0;
+            for (size_t j = 0; j < n; j++)
+                if (distances[j] > max_distance) max_distance = distances[j];
+        } else {
+            max_distance = v[max_num_hits - 1].d; /* :255 */
+        }
+        for (size_t j = 0; j < n; j++) /* :261-264 */
+            if (v[j].d <= max_distance && (max_divergence == ORC_NO_LIMIT || v[j].d <= (uint64_t)max_divergence)) rows++;
+        free(v);
+    }
+    free(tmp);
+    free(distances);
+    return rows;
+}
+
 int64_t orc_bench_besthit_codes(const uint8_t *subject_codes, size_t n, const uint8_t *query_codes, size_t q,
                                 size_t L, int64_t max_divergence) {
     uint32_t *distances = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));

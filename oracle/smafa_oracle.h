@@ -146,6 +146,9 @@ int orc_ws_from_ascii(orc_windowset *ws, const uint8_t *rows, size_t n, size_t L
 int orc_encode_rows(const uint8_t *rows, size_t n, size_t L, uint64_t *out);
 int64_t orc_bench_besthit_onehot(const orc_windowset *ws, const uint64_t *query_enc, size_t q, size_t len,
                                  int64_t max_divergence);
+/* the K branch's per-query work (src/lib.rs:242-295: tuple vector, full sort, k-th tuple, walk), max_num_hits >= 2 */
+int64_t orc_bench_kmode_onehot(const orc_windowset *ws, const uint64_t *query_enc, size_t q, size_t len,
+                               int64_t max_divergence, int64_t max_num_hits);
 int64_t orc_bench_besthit_codes(const uint8_t *subject_codes, size_t n, const uint8_t *query_codes, size_t q,
                                 size_t L, int64_t max_divergence);
 

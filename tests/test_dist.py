@@ -293,42 +293,64 @@ def test_bench_self_launch_spawns_ranks_on_cpu_only_host():
 
 
 @pytest.mark.gpu
-def test_bench_line_contract_on_a_small_workload():
-    """the JSON line the driver reads: the contract's fields, `roofline` and `cpu_baseline` objects, every side leg verified
-    (a small store: the BASELINE configs block only runs on the metric's own workload)"""
+def test_bench_line_contract_on_a_small_workload(tmp_path):
+    """the JSON line the driver reads: the LAST line of stdout, at most 4096 characters with EVERY leg present (the BASELINE
+    configs block runs at a hundredth of its sizes here), the contract's fields, `roofline` and `cpu_baseline` objects; the
+    full record (every leg in detail) in the file the line names, every side leg verified"""
     import json
 
-    r = _bench("--steps", "3", "--warmup", "1", "--db-rows", "300000", "--queries", "2048", "--cpu-seconds", "0.3", "--no-related")
+    full_path = str(tmp_path / "bench_full.json")
+    r = _bench("--steps", "3", "--warmup", "1", "--db-rows", "300000", "--queries", "2048", "--cpu-seconds", "0.3", "--no-related",
+               "--configs-scale", "0.01", "--full-record", full_path)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
+    lines = r.stdout.splitlines()
+    assert lines and lines[-1].startswith("{") and len([l for l in lines if l.startswith("{")]) == 1
+    assert len(lines[-1]) <= 4096, len(lines[-1])
+    out = json.loads(lines[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in out, key
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["verified"] is True and out["vs_baseline"] is None
     assert out["unit"] == "query seqs/s" and out["higher_is_better"] is True and out["dtype"] == "u32" and "workload" in out["config"]
-    assert abs(out["value"] - 2048 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6
+    assert abs(out["value"] - 2048 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-4
     assert out["roofline"]["bound"] == "valu" and out["roofline"]["kernel"].startswith("smafa::scan_")
+    assert 0 < out["roofline"]["hbm_stream"]["frac_wall"] < 1.0 and out["roofline"]["hbm_stream"]["rows_identical"] is True
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "query seqs/s" and cb["sample"]
-    st = out["stream"]
+    assert cb["kmode"]["value"] > 0 and cb["kmode"]["max_num_hits"] == 5
+    legs = out["legs"]
+    for name in ("unfiltered", "bound8", "bound14", "bound24", "besthit_mixed", "besthit_far", "host_api", "kth5", "kth50", "kth5_d5",
+                 "kth50_d5", "cfg1", "cfg2", "cfg2N", "cfg3", "cfg4"):
+        assert name in legs and legs[name][0] > 0, (name, legs.get(name))
+    for name in ("bound8", "bound14", "bound24"):
+        assert legs[name][2] is True
+    for name in ("besthit_mixed", "kth5", "kth50", "kth5_d5", "kth50_d5", "host_api", "cfg1", "cfg2", "cfg2N", "cfg3", "cfg4"):
+        assert legs[name][3] is True, (name, legs[name])
+    assert out["full_record"] == full_path
+    full = json.load(open(full_path))
+    assert full["value"] == pytest.approx(out["value"], rel=1e-6) and full["verified"] is True
+    st = full["stream"]
     assert st["roofline"]["bound"] == "hbm" and st["metric_store"]["rows_identical"] is True
     assert 0 < st["metric_store"]["streaming"]["frac_wall_streamed"] < 1.0
-    assert all(x["verified"] for x in out["loose_bounds"]) and out["besthit_unbounded"]["verified"] is True
-    assert out["host_api"]["rows_identical_to_device_launch"] is True and out["unfiltered"]["kernel_ms"] > 0
+    assert all(x["verified"] for x in full["loose_bounds"]) and full["besthit_unbounded"]["verified"] is True
+    assert full["host_api"]["rows_identical_to_device_launch"] is True and full["unfiltered"]["kernel_ms"] > 0
+    assert all(v["verified"] for k, v in full["kth"].items() if isinstance(v, dict))
+    assert all(v["verified"] for v in full["configs"].values())
 
 
 @pytest.mark.gpu
-def test_bench_self_launch_two_ranks_one_gpu_gloo():
+def test_bench_self_launch_two_ranks_one_gpu_gloo(tmp_path):
     import json
 
+    full_path = str(tmp_path / "bench_full.json")
     r = _bench("--gpus", "2", "--single-device", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--db-rows", "200000",
-               "--queries", "512", "--no-cpu-baseline", "--no-related")
+               "--queries", "512", "--no-cpu-baseline", "--no-related", "--full-record", full_path)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) <= 4096, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    out = json.load(open(full_path))
+    assert line["n_gpus"] == 2 and line["verified"] is True and line["gathered_bytes_per_rank_per_step"] == out["gathered_bytes_per_rank_per_step"]
     assert out["n_gpus"] == 2 and out["verified"] is True and out["steps"] == 2
     frac = out["roofline"]["frac"]  # claimed only where profiles/ holds counters of this workload and kernel
     assert out["roofline"]["bound"] == "valu" and (frac is None or 0 < frac <= 1.0)
@@ -368,10 +390,12 @@ def test_rccl_rehearsal_world_of_one(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     assert open(out).read() == want.stdout and want.stdout
     for collective in ("gather", "all_gather"):
+        full_path = str(tmp_path / ("bench_%s.json" % collective))
         r = _bench("--gpus", "1", "--rehearse-collectives", "--collective", collective, "--steps", "3", "--warmup", "2",
-                   "--db-rows", "200000", "--queries", "512")
+                   "--db-rows", "200000", "--queries", "512", "--full-record", full_path)
         assert r.returncode == 0, r.stderr[-3000:]
-        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert len(r.stdout.splitlines()[-1]) <= 4096
+        line = json.load(open(full_path))
         assert line["verified"] is True and line["n_gpus"] == 1 and line["steps"] == 3
         c = line["checks"]
         assert c["gather_block_is_own_buffer"] is True and c["rows_fit_gathered_width"] is True and c["gathered_rows_total"] == line["rows_per_step"]

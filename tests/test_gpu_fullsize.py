@@ -89,7 +89,36 @@ def test_query_scan_full_size(n, q, alphabet, D, max_subs, n_frac):
         grp = want_best[want_best["query"] == i]
         dmin = grp["dist"].min()
         assert best[best["query"] == i].tobytes() == grp[grp["dist"] == dmin].tobytes()
+    if n == 10_000_000 and q <= 100_000 and n_frac == 0.0:
+        kth_modes_full_size(store, subj, qry, alphabet)
     store.close()
+
+
+def kth_modes_full_size(store, subj, qry, alphabet):
+    """The K branch (src/lib.rs:242-295) at BASELINE size, no bound: k in {2, 5, 50} on 1 500 planted queries + 100 uniform-random
+    ones (no near subject at all).  Every row's distance recomputed; the k-th rule's invariants for every query (at least k
+    rows, fewer than k rows strictly below the largest reported distance, ordered by (query, dist, subject)); the complete
+    row lists of 12 sampled queries == the oracle's 10M distances put through the rule (bench.expected_with_k)."""
+    import bench
+
+    far = synth.subjects(100, 60, alphabet, seed=9, dup_frac=0.0)
+    kq = np.concatenate([qry[:1500], far])
+    pick = np.concatenate([np.arange(0, 1500, 150), [1500, 1599]])  # 10 planted + 2 far
+    dist = {int(qi): oracle.distances_codes(subj, kq[qi]) for qi in pick}
+    for k in (2, 5, 50):
+        rows = store.scan(kq, max_divergence=None, max_num_hits=k)
+        check_rows(rows, subj, kq, 60)
+        r3 = bench.rows3(rows)
+        assert bench.kth_rows_ok(np, subj, kq, r3, k, None, [])  # the invariants, every query
+        for qi in pick:
+            want = bench.expected_with_k(np, dist[int(qi)], k, None)
+            assert r3[r3[:, 0] == qi][:, 1:].tobytes() == want.tobytes(), (k, int(qi))
+    # with a bound the K branch prints only what is within both (src/lib.rs:261-264)
+    rows = store.scan(kq, max_divergence=4, max_num_hits=5)
+    r3 = bench.rows3(rows)
+    assert bench.kth_rows_ok(np, subj, kq, r3, 5, 4, [])
+    for qi in pick:
+        assert r3[r3[:, 0] == qi][:, 1:].tobytes() == bench.expected_with_k(np, dist[int(qi)], 5, 4).tobytes()
 
 
 def test_query_scan_50m_store_one_rank_share():

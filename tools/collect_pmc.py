@@ -38,10 +38,17 @@ def run(cmd, log):
 
 
 def bench_line(log):
+    """the FULL record of the bench run behind `log` (bench.py prints a compact line and names the file that holds the rest)"""
     for line in open(log, errors="replace"):
         line = line.strip()
         if line.startswith("{") and '"metric"' in line:
-            return json.loads(line)
+            short = json.loads(line)
+            path = short.get("full_record")
+            if path:
+                path = path if os.path.isabs(path) else os.path.join(ROOT, path)
+                if os.path.exists(path):
+                    return json.load(open(path))
+            return short
     return None
 
 
@@ -56,7 +63,8 @@ def counter_rows(out_dir):
 def per_call(rows, calls):
     """counter totals over EVERY scan kernel dispatch of the run, divided by the number of identical calls the run made
     (mode besthit: one smafa_scan_hits call is a ladder of scans; cluster: calls = 1, the whole run)"""
-    mine = [r for r in rows if "smafa::scan_" in r["Kernel_Name"]]
+    # (the k-th modes' bound kernel and row filter belong to the call as well)
+    mine = [r for r in rows if any(k in r["Kernel_Name"] for k in ("smafa::scan_", "kth_from_counts_kernel", "filter_rows_kernel"))]
     if not mine:
         return {}, 0, 0.0, {}
     disp, by_kernel = {}, {}
@@ -115,7 +123,7 @@ def main():
     record = {"command": " ".join(bench[1:]).replace(ROOT + "/", "")}
     if not a.skip_stats:
         rc = run([prof, "--kernel-trace", "--stats", "-d", os.path.join(out, "stats"), "-o", "stats", "--output-format", "csv",
-                  "--", *bench], os.path.join(out, "stats.log"))
+                  "--", *bench, "--full-record", os.path.join(out, "stats_full.json")], os.path.join(out, "stats.log"))
         print("stats pass rc", rc, flush=True)
         line = bench_line(os.path.join(out, "stats.log"))
         if line:
@@ -129,8 +137,8 @@ def main():
     merged, n_disp, kernel, cfg, ms_prof, by_kernel = {}, {}, None, None, {}, {}
     for name, counters in passes:
         d = os.path.join(out, name)
-        rc = run([prof, "--pmc", *counters, "--kernel-trace", "-d", d, "-o", name, "--output-format", "csv", "--", *bench],
-                 os.path.join(out, name + ".log"))
+        rc = run([prof, "--pmc", *counters, "--kernel-trace", "-d", d, "-o", name, "--output-format", "csv", "--", *bench,
+                  "--full-record", os.path.join(out, name + "_full.json")], os.path.join(out, name + ".log"))
         print(name, "pass rc", rc, flush=True)
         line = bench_line(os.path.join(out, name + ".log"))
         if not line:
@@ -139,7 +147,7 @@ def main():
         kernel = line["roofline"]["kernel"].split(" (")[0]  # (a note like " (zone level on)" is not part of the symbol)
         cfg = line["config"]
         record["build_id"] = line.get("build_id")
-        if cfg.get("mode") == "besthit":  # one call = a ladder of scans: totals over all scan kernels per call
+        if cfg.get("mode") in ("besthit", "kth"):  # one call = several scans: totals over all scan kernels per call
             avg, nd, ms, bk = per_call(counter_rows(d), line["calls_total"])
             by_kernel[name] = bk
         else:
@@ -157,7 +165,7 @@ def main():
         "config": {"db_rows": cfg["db_rows"], "seq_len": cfg["seq_len"], "queries": cfg["queries_per_gpu"],
                    "max_div": cfg["max_divergence"], "alphabet": cfg["alphabet"], "store": cfg.get("store", "uniform"),
                    "n_frac": cfg.get("n_frac", 0.0), "prefilter": cfg.get("prefilter", 1), "mode": cfg.get("mode", "scan"),
-                   "far_frac": cfg.get("far_frac", 0.5)},
+                   "far_frac": cfg.get("far_frac", 0.5), "kth_k": cfg.get("kth_k", 0), "kth_bounded": cfg.get("kth_bounded", False)},
         "by_kernel_per_call": by_kernel.get("sq_a"),
         "per_launch": merged,
         "dispatches_averaged": n_disp,
