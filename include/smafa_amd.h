@@ -166,6 +166,11 @@ int smafa_last_scan_ms(smafa_db *db, float *ms, uint32_t *n_launches);
 /* Totals over the most recent smafa_scan_hits call on this handle (a best-hit or k-th call without a tight bound is
  * several scans: the near-hit ladder, then the tightening path): device time of the scan kernels, kernel launches, scans. */
 int smafa_last_call_stats(smafa_db *db, float *kernel_ms, uint32_t *n_launches, uint32_t *n_scans);
+/* Where this handle's scan kernels were really launched: the HIP device that was current on the launching host thread at
+ * the most recent launch (-1: none yet), and how many launches of the handle's life were issued while another device than
+ * smafa_db_info().device was current (must stay 0).  A multi-device caller — smafa_group_*, smafa_cluster_multi, one host
+ * thread per member — checks with this that replica g really runs on devices[g] and not silently on device 0. */
+int smafa_launch_device(smafa_db *db, int *device_at_last_launch, uint64_t *launches_off_device);
 /* How the most recent scan kernel launch on this handle was laid out: whether it kept only the prefilter's plane
  * of each subject resident (then a sparse-hit scan streams words_per_plane*4 bytes per subject instead of
  * bytes_per_subject), wave tiles per wave, and query blocks (= passes over the store). */

@@ -26,7 +26,7 @@ EXPORTS = [
     "smafa_last_error", "smafa_device_count", "smafa_set_verbosity", "smafa_encode", "smafa_decode",
     "smafa_db_create", "smafa_db_append", "smafa_db_save", "smafa_db_load", "smafa_db_info", "smafa_db_set_stream", "smafa_db_destroy",
     "smafa_scan_hits", "smafa_distances", "smafa_qset_create", "smafa_qset_destroy", "smafa_scan_launch",
-    "smafa_scan_each", "smafa_last_call_stats",
+    "smafa_scan_each", "smafa_last_call_stats", "smafa_launch_device",
     "smafa_sync", "smafa_last_scan_ms", "smafa_last_scan_plan", "smafa_last_scan_kernel", "smafa_build_id", "smafa_hbm_read_probe", "smafa_set_query_block", "smafa_set_prefilter", "smafa_set_zone_level", "smafa_select_rows", "smafa_write_rows",
     "smafa_dbfile_write", "smafa_dbfile_read", "smafa_fastx_load", "smafa_fastx_load_partial", "smafa_fastx_load_part", "smafa_free",
     "smafa_group_create", "smafa_group_load", "smafa_group_append", "smafa_group_scan_hits", "smafa_group_size",
@@ -99,6 +99,7 @@ def lib() -> C.CDLL:
     l.smafa_scan_launch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp]
     l.smafa_scan_each.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint64, vp, C.c_int]
     l.smafa_last_call_stats.argtypes = [vp, C.POINTER(C.c_float), u32p, u32p]
+    l.smafa_launch_device.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
     l.smafa_sync.argtypes = [vp]
     l.smafa_last_scan_ms.argtypes = [vp, C.POINTER(C.c_float), u32p]
     l.smafa_last_scan_plan.argtypes = [vp, u32p, u32p, u32p]

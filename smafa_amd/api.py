@@ -180,6 +180,12 @@ class SubjectStore:
         check(lib().smafa_last_call_stats(self._h, C.byref(ms), C.byref(n), C.byref(k)))
         return {"kernel_ms": ms.value, "launches": n.value, "scans": k.value}
 
+    def launch_device(self) -> tuple[int, int]:
+        """(HIP device current on the launching thread at the last scan launch, launches issued off the handle's device)"""
+        dev, off = C.c_int(-1), C.c_uint64(0)
+        check(lib().smafa_launch_device(self._h, C.byref(dev), C.byref(off)))
+        return dev.value, off.value
+
     def sync(self) -> None:
         check(lib().smafa_sync(self._h))
 
@@ -233,6 +239,18 @@ class SubjectGroup:
 
     def __len__(self) -> int:
         return lib().smafa_group_size(self._h)
+
+    def members(self):
+        """per member: (smafa_db_info().device, device current at its last scan launch, launches off its device)"""
+        out = []
+        for g in range(len(self)):
+            h = lib().smafa_group_member(self._h, g)
+            info = _lib.DbInfo()
+            check(lib().smafa_db_info(h, C.byref(info)))
+            dev, off = C.c_int(-1), C.c_uint64(0)
+            check(lib().smafa_launch_device(h, C.byref(dev), C.byref(off)))
+            out.append((int(info.device), dev.value, off.value))
+        return out
 
     def push(self, codes: np.ndarray) -> None:
         c = np.ascontiguousarray(codes, dtype=np.uint8)

@@ -5,6 +5,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -57,9 +58,12 @@ struct DevBuf {
 
 using namespace smafa;
 
+static std::atomic<uint64_t> g_qset_serial{1};
+
 struct smafa_qset {
     smafa_db *db = nullptr;
     uint64_t nq = 0;
+    uint64_t serial = 0;  // unique per fill of the set: a recreated set at a recycled address is a different set
     DevBuf qrec, thr, cnt;  // packed records, per-query bounds, per-query distance histograms (k >= 2 only)
 };
 
@@ -80,11 +84,17 @@ struct smafa_db {
     // path are several scans): smafa_last_call_stats
     float call_ms = 0.f;
     uint32_t call_launches = 0, call_scans = 0;
+    // Where the scan launches of this handle really went: the HIP device current on the launching thread at each launch
+    // (smafa_launch_device).  A member of a multi-device group whose worker thread forgot hipSetDevice would show here.
+    int launch_device = -1;
+    uint64_t launches_off_device = 0;
     double life_ms = 0.0;        // ... and over the handle's life (the cluster driver's debug line)
     uint64_t life_launches = 0;
     // smafa_scan_each: the K one-query launches captured once as a HIP graph and replayed
     hipGraphExec_t each_graph = nullptr;
-    struct EachKey { const void *qs, *hits, *counts; uint64_t cap, nq, generation; uint32_t max_div, qb; int zone; bool filter; } each_key{};
+    // (the captured kernel nodes bake in the set's device record buffer: the key names the set by its serial and that pointer,
+    // not by its host address alone — a destroyed set's address is handed out again by the next `new`)
+    struct EachKey { const void *qs, *qrec, *hits, *counts; uint64_t qs_serial, cap, nq, generation; uint32_t max_div, qb; int zone; bool filter; } each_key{};
     uint32_t qb_override = 0;
     bool use_filter = true;  // exact lower-bound prefilter in the scan kernel (SMAFA_FILTER=0 disables)
     uint32_t tiles_override = 0;  // SMAFA_TILES
@@ -408,6 +418,7 @@ static int reserve_tiles(smafa_db *db, uint64_t need_tiles) {
 static int qset_fill(smafa_qset *qs, smafa_db *db, const uint8_t *query_codes, uint64_t n_queries) {
     qs->db = db;
     qs->nq = n_queries;
+    qs->serial = g_qset_serial.fetch_add(1);
     const uint64_t padded = std::max<uint64_t>((n_queries + 63) / 64 * 64, 64);
     int rc = qs->qrec.ensure(padded * db->QS * sizeof(uint32_t));
     if (!rc) rc = qs->thr.ensure(padded * sizeof(uint32_t));
@@ -721,6 +732,11 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     const uint64_t grid = n_qblocks * a.n_wg_tiles;
     if (grid > 0x7fffffffull)
         return set_error(SMAFA_ERR_INVALID, "scan grid too large (%llu workgroups)", (unsigned long long)grid);
+    int cur_dev = -1;
+    if (hipGetDevice(&cur_dev) == hipSuccess) {
+        db->launch_device = cur_dev;
+        if (cur_dev != db->device) db->launches_off_device++;
+    }
     launch_scan(db, qs->qrec.as<uint32_t>(), a, (uint32_t)grid, T, lazy, zone);
     db->plan_lazy = lazy ? 1u : 0u;
     db->plan_tiles = T;
@@ -1041,7 +1057,9 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
         // from their subject, 10 000 x 10M aa: 35 ms with both, profiles/r02_besthit_ladder.txt)
         // (three planes and more: a step at 17, the top of FOLD 1's range — 12 ms where the step at 30 costs 15 — is there for
         // the planner below to choose when most open queries lie within it)
-        if (db->P >= 3) ladder.push_back(17u);
+        // — only where the planner will run (plan_later_steps needs 2048 open queries): a small batch would otherwise run the
+        // steps at 17 AND 30 back to back, which the measurement above found redundant
+        if (db->P >= 3 && n_queries >= 2048) ladder.push_back(17u);
         ladder.push_back(db->P >= 3 ? 30u : 16u);
     }
     const uint32_t limit = std::min<uint32_t>(max_div, db->L);
@@ -1590,6 +1608,10 @@ int smafa_qset_create(smafa_qset **out, smafa_db *db, const uint8_t *query_codes
 void smafa_qset_destroy(smafa_qset *qs) {
     if (!qs) return;
     if (qs->db) (void)hipSetDevice(qs->db->device);
+    if (qs->db && qs->db->each_graph && qs->db->each_key.qs == qs) {  // the captured passes read this set's records
+        (void)hipGraphExecDestroy(qs->db->each_graph);
+        qs->db->each_graph = nullptr;
+    }
     qs->qrec.release();
     qs->thr.release();
     qs->cnt.release();
@@ -1661,7 +1683,8 @@ int smafa_scan_each(smafa_db *db, smafa_qset *qs, uint32_t max_div, void *d_hits
     }
     smafa_db::EachKey key;
     memset(&key, 0, sizeof key);  // (padding bytes take part in the comparison below)
-    key.qs = qs, key.hits = d_hits, key.counts = d_counts, key.cap = cap_per_query, key.nq = qs->nq, key.generation = db->generation;
+    key.qs = qs, key.qrec = qs->qrec.p, key.qs_serial = qs->serial;
+    key.hits = d_hits, key.counts = d_counts, key.cap = cap_per_query, key.nq = qs->nq, key.generation = db->generation;
     key.max_div = max_div, key.qb = db->qb_override, key.zone = db->zone, key.filter = db->use_filter;
     if (!db->each_graph || memcmp(&key, &db->each_key, sizeof key) != 0) {
         if (db->each_graph) (void)hipGraphExecDestroy(db->each_graph);
@@ -1701,6 +1724,15 @@ int smafa_last_call_stats(smafa_db *db, float *kernel_ms, uint32_t *n_launches, 
     return SMAFA_OK;
 } catch (...) {
     return smafa::exception_code("smafa_last_call_stats");
+}
+
+int smafa_launch_device(smafa_db *db, int *device_at_last_launch, uint64_t *launches_off_device) try {
+    if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_launch_device: NULL handle");
+    if (device_at_last_launch) *device_at_last_launch = db->launch_device;
+    if (launches_off_device) *launches_off_device = db->launches_off_device;
+    return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_launch_device");
 }
 
 int smafa_sync(smafa_db *db) try {

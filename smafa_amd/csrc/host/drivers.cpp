@@ -668,6 +668,106 @@ static int cluster_run(const ClusterInput &in, uint32_t max_divergence, int out_
         rc = smafa_db_create(&centroids.db, device, alphabet, Lw);
         if (rc) return rc;
 
+        // ---- output stage, overlapped with the scans (src/cluster.rs:79-84).  A record's line is final as soon as the batch
+        // that holds it is resolved (records are resolved in input order; duplicates print nothing), so rank 0 formats and
+        // writes the lines of finished batches on a writer thread while the next batches scan.  Every line is
+        // "raw record \t centroid string \n" = 2L + 2 bytes; blocks of lines are formatted by all threads and written in order.
+        centroid_rec.reserve(uniq.size());  // the writer reads entries while the main loop appends: never reallocated
+        struct Progress {
+            std::mutex m;
+            std::condition_variable cv;
+            uint64_t final_upto = 0;  // records [0, final_upto) have their final centroid_of / centroid_rec entries
+            bool stop = false;        // the main loop failed: write nothing more
+        } prog;
+        int write_rc = SMAFA_OK;
+        std::string write_msg;
+        size_t lines_written = 0;
+        double t_write_busy = 0.0;
+        auto writer_body = [&]() noexcept {
+            try {
+                char letters[32];
+                for (int c = 0; c < 32; c++) letters[c] = letter_of(alphabet, (uint8_t)c);
+                const size_t line_bytes = 2 * L + 2, block_records = 1u << 20;
+                const unsigned T = n >= (1u << 16) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+                std::vector<char> text;
+                std::vector<uint32_t> lines;
+                uint64_t done = 0;
+                while (done < n) {
+                    uint64_t upto;
+                    {
+                        std::unique_lock<std::mutex> lock(prog.m);
+                        prog.cv.wait(lock, [&] { return prog.stop || prog.final_upto > done; });
+                        if (prog.stop) return;
+                        upto = std::min<uint64_t>(prog.final_upto, done + block_records);
+                    }
+                    const double t0 = now_seconds();
+                    lines.clear();
+                    for (uint64_t i = done; i < upto; i++)
+                        if (centroid_of[i] != UINT32_MAX) lines.push_back((uint32_t)i);
+                    const size_t nk = lines.size();
+                    if (text.size() < nk * line_bytes) text.resize(nk * line_bytes);
+                    auto fill = [&](unsigned t, unsigned of) {
+                        for (size_t k = nk * t / of, e = nk * (t + 1) / of; k < e; k++) {
+                            const uint32_t i = lines[k];
+                            char *o = &text[k * line_bytes];
+                            memcpy(o, &raw[(size_t)i * L], L);
+                            o[L] = '\t';
+                            const uint8_t *c = &codes[(size_t)centroid_rec[centroid_of[i]] * L];
+                            for (size_t j = 0; j < L; j++) o[L + 1 + j] = letters[c[j] & 31];
+                            o[2 * L + 1] = '\n';
+                        }
+                    };
+                    const unsigned use = nk >= (1u << 14) ? T : 1u;
+                    if (use == 1) {
+                        fill(0, 1);
+                    } else {
+                        std::vector<std::thread> pool;
+                        pool.reserve(use);
+                        for (unsigned t = 0; t < use; t++) pool.emplace_back(fill, t, use);
+                        for (auto &th : pool) th.join();
+                    }
+                    if (nk) {
+                        write_rc = write_all(out_fd, text.data(), nk * line_bytes);
+                        if (write_rc) {
+                            write_msg = smafa_last_error();
+                            return;
+                        }
+                    }
+                    lines_written += nk;
+                    done = upto;
+                    t_write_busy += now_seconds() - t0;
+                }
+            } catch (...) {
+                write_rc = smafa::exception_code("the cluster output thread");
+                try {
+                    write_msg = smafa_last_error();
+                } catch (...) {
+                }
+            }
+        };
+        std::thread writer;
+        struct WriterGuard {  // whatever way the function is left: the writer is told to stop and joined
+            Progress &p;
+            std::thread &th;
+            ~WriterGuard() {
+                if (!th.joinable()) return;
+                {
+                    std::lock_guard<std::mutex> lock(p.m);
+                    p.stop = true;
+                }
+                p.cv.notify_all();
+                th.join();
+            }
+        } writer_guard{prog, writer};
+        if (rank == 0) writer = std::thread(writer_body);
+        auto publish = [&](uint64_t upto) {
+            {
+                std::lock_guard<std::mutex> lock(prog.m);
+                prog.final_upto = upto;
+            }
+            prog.cv.notify_all();
+        };
+
         std::vector<uint8_t> batch_codes, cand_codes, new_codes;
         std::vector<smafa_hit> old_hits, cand_hits;
         std::vector<uint32_t> cand_pos;        // candidate ordinal -> position in the batch
@@ -794,6 +894,8 @@ static int cluster_run(const ClusterInput &in, uint32_t max_divergence, int out_
             }
             t_append += now_seconds() - t0;
             pos += nb;
+            // every record in front of the next unseen one is final now (the records between two first occurrences are duplicates)
+            if (rank == 0) publish(pos < uniq.size() ? uniq[pos] : n);
             // batch size follows the row volume: grow while the scans stay cheap, shrink on dense input
             // (from exchanged quantities only, so every rank takes the same decision)
             const size_t volume = (nb - cand_pos.size()) + cand_hits.size();
@@ -810,44 +912,21 @@ static int cluster_run(const ClusterInput &in, uint32_t max_divergence, int out_
             db_life_stats(cand.db, &ms_b, &lb);
             log_line(2, "scan kernels %.1f ms over %llu launches (vs old centroids %.1f ms, vs candidates %.1f ms)", ms_a + ms_b,
                      (unsigned long long)(la + lb), ms_a, ms_b);
+            // where this rank's launches really went (a multi-device run must not end up with every replica on device 0)
+            int at = -1, at_c = -1;
+            uint64_t off = 0, off_c = 0;
+            smafa_launch_device(centroids.db, &at, &off);
+            if (cand.db) smafa_launch_device(cand.db, &at_c, &off_c);
+            log_line(2, "rank %u of %u: handle on device %d, scan launches issued with device %d current, %llu off the handle's device",
+                     rank, world, device, at, (unsigned long long)(off + off_c));
         }
-        // src/cluster.rs:79-84.  Every line is "raw record \t centroid string \n" = 2L + 2 bytes, so line k of the
-        // output sits at byte k * (2L + 2): blocks of lines are formatted by all threads and written in order.
-        if (rank == 0) {
+        if (rank == 0) {  // the writer finishes the lines of the last batches
             const double t_out = now_seconds();
-            std::vector<uint32_t> lines;  // records that print (duplicates do not), input order
-            lines.reserve(uniq.size());
-            for (uint64_t i = 0; i < n; i++)
-                if (centroid_of[i] != UINT32_MAX) lines.push_back((uint32_t)i);
-            char letters[32];
-            for (int c = 0; c < 32; c++) letters[c] = letter_of(alphabet, (uint8_t)c);
-            const size_t line_bytes = 2 * L + 2, block_lines = 1u << 20;
-            const unsigned T = lines.size() >= (1u << 16) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-            std::vector<char> text(std::min(block_lines, lines.size()) * line_bytes);
-            for (size_t k0 = 0; k0 < lines.size(); k0 += block_lines) {
-                const size_t nk = std::min(block_lines, lines.size() - k0);
-                auto fill = [&](unsigned t) {
-                    for (size_t k = nk * t / T, e = nk * (t + 1) / T; k < e; k++) {
-                        const uint32_t i = lines[k0 + k];
-                        char *o = &text[k * line_bytes];
-                        memcpy(o, &raw[(size_t)i * L], L);
-                        o[L] = '\t';
-                        const uint8_t *c = &codes[(size_t)centroid_rec[centroid_of[i]] * L];
-                        for (size_t j = 0; j < L; j++) o[L + 1 + j] = letters[c[j] & 31];
-                        o[2 * L + 1] = '\n';
-                    }
-                };
-                if (T == 1) {
-                    fill(0);
-                } else {
-                    std::vector<std::thread> pool;
-                    for (unsigned t = 0; t < T; t++) pool.emplace_back(fill, t);
-                    for (auto &th : pool) th.join();
-                }
-                rc = write_all(out_fd, text.data(), nk * line_bytes);
-                if (rc) return rc;
-            }
-            log_line(2, "%zu lines written in %.2f s", lines.size(), now_seconds() - t_out);
+            publish(n);
+            writer.join();
+            if (write_rc) return set_error(write_rc, "%s", write_msg.c_str());
+            log_line(2, "%zu lines written in %.2f s (%.2f s of formatting + writing overlapped with the scans, %.2f s after the last batch)",
+                     lines_written, t_write_busy, t_write_busy - std::min(t_write_busy, now_seconds() - t_out), now_seconds() - t_out);
         }
         log_line(1, "Clustering complete, took %llu seconds. Clustered %llu sequences into %zu clusters.",  // src/cluster.rs:87-92
                  (unsigned long long)(now_seconds() - t_start), (unsigned long long)n, centroid_rec.size());
@@ -931,19 +1010,37 @@ int smafa_cluster_multi(const char *input_fasta, uint32_t max_divergence, int ou
     std::vector<std::string> msgs((size_t)ndev);
     std::vector<ThreadRank> ranks((size_t)ndev);
     std::vector<std::thread> pool;
-    for (int r = 0; r < ndev; r++) {
-        ranks[r] = {&ex, (uint32_t)r};
-        pool.emplace_back([&, r] {
-            rcs[r] = cluster_run(in, max_divergence, out_fd, devices[r], alphabet, (uint32_t)r, (uint32_t)ndev, thread_allgather, &ranks[r]);
-            if (rcs[r]) {
-                msgs[r] = smafa_last_error();  // the text is per thread
-                std::lock_guard<std::mutex> lock(ex.m);
-                ex.failed = true;  // nobody waits for a rank that has left
-                ex.cv.notify_all();
-            }
-        });
+    auto leave = [&] {  // nobody waits for a rank that has left
+        std::lock_guard<std::mutex> lock(ex.m);
+        ex.failed = true;
+        ex.cv.notify_all();
+    };
+    int start_rc = SMAFA_OK;
+    try {
+        pool.reserve((size_t)ndev);
+        for (int r = 0; r < ndev; r++) {
+            ranks[r] = {&ex, (uint32_t)r};
+            pool.emplace_back([&, r]() noexcept {
+                try {
+                    rcs[r] = cluster_run(in, max_divergence, out_fd, devices[r], alphabet, (uint32_t)r, (uint32_t)ndev, thread_allgather, &ranks[r]);
+                } catch (...) {  // no exception ends a rank's thread (std::terminate): it becomes the rank's error code
+                    rcs[r] = smafa::exception_code("a cluster rank's thread");
+                }
+                if (rcs[r]) {
+                    try {
+                        msgs[r] = smafa_last_error();  // the text is per thread
+                    } catch (...) {
+                    }
+                    leave();
+                }
+            });
+        }
+    } catch (...) {  // a thread could not be started: the ranks already running must not wait for it, and are joined
+        start_rc = smafa::exception_code("starting a cluster rank's thread");
+        leave();
     }
     for (auto &th : pool) th.join();
+    if (start_rc) return start_rc;
     // every rank reports the same input-borne failure; a rank-local one (a device) is the first one's to tell
     for (int r = 0; r < ndev; r++)
         if (rcs[r] && msgs[r].find("allgather failed") == std::string::npos) return set_error(rcs[r], "%s", msgs[r].c_str());

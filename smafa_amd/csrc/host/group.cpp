@@ -23,6 +23,7 @@ struct smafa_group {
     uint64_t retry_nq = 0, generation = 0, retry_generation = 0;
     uint32_t retry_div = 0, retry_k = 0;
     bool retry_valid = false;
+    bool poisoned = false;  // an append failed on some member: the replicas may hold different rows, no scan may mix them
 };
 
 namespace smafa {
@@ -33,16 +34,32 @@ int group_on_every_handle(smafa_group *grp, const std::function<int(int)> &fn) {
     const int ndev = (int)grp->dbs.size();
     std::vector<int> rcs((size_t)ndev, SMAFA_OK);
     std::vector<std::string> msgs((size_t)ndev);
-    auto body = [&](int g) {
-        rcs[g] = fn(g);
-        if (rcs[g]) msgs[g] = smafa_last_error();
+    auto body = [&](int g) noexcept {
+        try {
+            rcs[g] = fn(g);
+        } catch (...) {  // no exception ends a worker thread (std::terminate): it becomes this member's error code
+            rcs[g] = exception_code("a group member's worker thread");
+        }
+        if (rcs[g]) {
+            try {
+                msgs[g] = smafa_last_error();
+            } catch (...) {
+            }
+        }
     };
     if (ndev == 1) {
         body(0);
     } else {
         std::vector<std::thread> pool;
-        for (int g = 0; g < ndev; g++) pool.emplace_back(body, g);
+        int started = 0, start_rc = SMAFA_OK;
+        try {
+            pool.reserve((size_t)ndev);
+            for (; started < ndev; started++) pool.emplace_back(body, started);
+        } catch (...) {  // a thread could not be created: the ones already running are joined before anything propagates
+            start_rc = exception_code("starting a group member's worker thread");
+        }
         for (auto &th : pool) th.join();
+        if (start_rc) return start_rc;
     }
     for (int g = 0; g < ndev; g++)
         if (rcs[g]) return set_error(rcs[g], "%s", msgs[g].c_str());
@@ -118,9 +135,16 @@ int smafa_group_load(smafa_group **out, const int *devices, int ndev, const char
 
 int smafa_group_append(smafa_group *grp, const uint8_t *codes, uint64_t n) try {
     if (!grp || (!codes && n)) return set_error(SMAFA_ERR_INVALID, "smafa_group_append: NULL argument");
+    if (grp->poisoned) return set_error(SMAFA_ERR_INVALID, "smafa_group_append: an earlier append failed on some member; the group is unusable");
     grp->generation++;
     // every replica receives the same rows in the same order: subject indices agree across the members
-    return group_on_every_handle(grp, [&](int g) { return smafa_db_append(grp->dbs[g], codes, n); });
+    int rc = group_on_every_handle(grp, [&](int g) { return smafa_db_append(grp->dbs[g], codes, n); });
+    if (rc) {  // some replicas may have taken the rows and others not: later scans would mix different stores
+        const std::string why = smafa_last_error();
+        grp->poisoned = true;
+        return set_error(rc, "%s", why.c_str());
+    }
+    return SMAFA_OK;
 } catch (...) {
     return smafa::exception_code("smafa_group_append");
 }
@@ -138,6 +162,8 @@ int smafa_group_scan_hits(smafa_group *grp, const uint8_t *query_codes, uint64_t
         return set_error(SMAFA_ERR_INVALID, "smafa_group_scan_hits: NULL argument");
     if (n_queries > 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many queries in one batch");
     if (max_num_hits == 0) max_num_hits = SMAFA_NONE;
+    if (grp->poisoned)
+        return set_error(SMAFA_ERR_INVALID, "smafa_group_scan_hits: an append failed on some member; the replicas may differ");
     const int ndev = (int)grp->dbs.size();
     smafa_db_info_t info;
     int rc = smafa_db_info(grp->dbs[0], &info);

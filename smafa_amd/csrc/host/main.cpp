@@ -20,9 +20,9 @@
 
 #include "../../../include/smafa_amd.h"
 
-static int usage(const char *msg) {
+static int usage(const char *msg, FILE *to = stderr) {
     if (msg) fprintf(stderr, "error: %s\n\n", msg);
-    fprintf(stderr,
+    fprintf(to,
             "Usage: smafa <COMMAND>\n\n"
             "Commands:\n"
             "  makedb   Generate a searchable database\n"
@@ -51,10 +51,20 @@ static bool parse_u32(const char *s, uint32_t *out) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 2) return usage(nullptr);
-    const std::string cmd = argv[1];
+    // top-level -v/--verbose and -q/--quiet in front of the subcommand (src/main.rs:67-68); the reference takes its log level
+    // from the subcommand's own flags (set_log_level(m, true), :17,34,40,47), so these are accepted and change nothing
+    int first = 1;
+    while (first < argc && (!strcmp(argv[first], "-v") || !strcmp(argv[first], "--verbose") || !strcmp(argv[first], "-q") ||
+                            !strcmp(argv[first], "--quiet")))
+        first++;
+    if (first >= argc) {  // no subcommand: the help text on stdout, and success (src/main.rs:52-56)
+        usage(nullptr, stdout);
+        printf("\n");
+        return 0;
+    }
+    const std::string cmd = argv[first];
     if (cmd == "-h" || cmd == "--help") {
-        usage(nullptr);
+        usage(nullptr, stdout);
         return 0;
     }
     const bool is_cluster = cmd == "cluster";
@@ -66,7 +76,7 @@ int main(int argc, char **argv) {
     int alphabet = SMAFA_ALPHABET_NT;
     int verbosity = 1;  // the reference logs at info level unless told otherwise (bird_tool_utils set_log_level)
     if (const char *e = getenv("SMAFA_LOG")) verbosity = atoi(e);
-    for (int i = 2; i < argc; i++) {
+    for (int i = first + 1; i < argc; i++) {
         const std::string a = argv[i];
         auto value = [&]() -> const char * { return i + 1 < argc ? argv[++i] : nullptr; };
         if (a == "-i" || a == "--input") {
@@ -127,7 +137,7 @@ int main(int argc, char **argv) {
         } else if (a == "--quiet") {
             verbosity = 0;  // errors only
         } else if (a == "-h" || a == "--help") {
-            usage(nullptr);
+            usage(nullptr, stdout);
             return 0;
         } else {
             return usage(("unexpected argument " + a).c_str());

@@ -5,7 +5,9 @@
 //   byte 0      varint(3)        the reference reads its version from bytes 0..4 (src/lib.rs:214) and rejects this file with
 //                                its own "Unsupported db file version: 3." panic, as it should
 //   byte 1      varint(2)        kind: 2 = packed tiles (kind 1 is the raw amino-acid code container of dbfile.cpp)
-//   bytes 2..7  "SMAFA\0"
+//   bytes 2..6  "SMAFA"
+//   byte 7      layout revision  1 = 32-bit column table (perm u32[W*32]); 0 = the 16-bit table of earlier builds: refused
+//                                by name ("written by an older build"), not by whatever check its bytes happen to fail
 //   byte 8      PackedHeader     little-endian, fixed width; every section starts on a 4096-byte boundary
 //   sections    perm  u32[W*32]  packed column j holds source column perm[j]          (layout, engine.hip choose_layout)
 //               tab   u8[L*32]   [source column][code] -> stored code
@@ -29,9 +31,11 @@
 
 namespace smafa {
 
-static const char kMagic[8] = {0x03, 0x02, 'S', 'M', 'A', 'F', 'A', 0};
+constexpr char kLayoutRevision = 1;
+static const char kMagic[8] = {0x03, 0x02, 'S', 'M', 'A', 'F', 'A', kLayoutRevision};
 
-bool is_packed_file(const uint8_t *p, size_t len) { return len >= sizeof kMagic && memcmp(p, kMagic, sizeof kMagic) == 0; }
+// any revision of the packed store file (the revision itself is checked, with its own message, by PackedStore::open)
+bool is_packed_file(const uint8_t *p, size_t len) { return len >= sizeof kMagic && memcmp(p, kMagic, sizeof kMagic - 1) == 0; }
 
 PackedStore::~PackedStore() {
     if (map_) munmap(map_, map_len_);
@@ -52,6 +56,10 @@ int PackedStore::open(const char *path) {
     map_len_ = (size_t)st.st_size;
     const uint8_t *p = (const uint8_t *)m;
     if (!is_packed_file(p, map_len_)) return set_error(SMAFA_ERR_FORMAT, "%s: not a packed store file", path);
+    if ((char)p[sizeof kMagic - 1] != kLayoutRevision)
+        return set_error(SMAFA_ERR_FORMAT, "%s: packed store written by %s build (layout revision %u, this build reads %u): re-run makedb --packed",
+                         path, (char)p[sizeof kMagic - 1] < kLayoutRevision ? "an older" : "a newer", (unsigned)p[sizeof kMagic - 1],
+                         (unsigned)kLayoutRevision);
     memcpy(&h, p + sizeof kMagic, sizeof h);
     // ---- everything a reader (host decode, device kernels) indexes with is checked here, once
     const uint64_t L = h.seq_len, W = h.words, P = h.planes;

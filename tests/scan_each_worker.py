@@ -61,7 +61,30 @@ def main():
     store.sync()
     assert int(counts[3].item()) == int((want["query"] == 3).sum()) and int(counts[3].item()) > 8
     assert any("scan_zone_few_kernel" in k for k in kernels) and any("scan_lazy_kernel" in k or "scan_kernel" in k for k in kernels), kernels
+    # a query set destroyed and another one of the SAME size created (the allocator may hand out the same host address and
+    # the same device buffer): the graph captured for the first must not be replayed for the second
+    store.set_zone_level(1)
+    store.scan_each(qs, D, hits.data_ptr(), cap, counts.data_ptr(), use_graph=True)
+    store.sync()
     qs.close()
+    qry_b, _, _ = synth.queries(subj, nq, 1, seed=33, max_subs=4)
+    want_b = oracle.scan_codes(subj, qry_b, D)
+    assert want_b.tobytes() != want.tobytes()
+    qs_b = smafa_amd.QuerySet(store, qry_b)
+    for rep in range(2):
+        counts.fill_(-1)
+        torch.cuda.synchronize()
+        store.scan_each(qs_b, D, hits.data_ptr(), cap, counts.data_ptr(), use_graph=True)
+        store.sync()
+        c = counts.cpu().numpy()
+        h = hits.cpu().numpy().view(np.uint32).reshape(nq, cap, 3)
+        for q in range(nq):
+            w = want_b[want_b["query"] == q]
+            assert c[q] == len(w), ("recreated set", rep, q, c[q], len(w))
+            r = h[q, : c[q]]
+            r = r[np.lexsort((r[:, 1], r[:, 2], r[:, 0]))]
+            assert r.tobytes() == rows3(w).tobytes(), ("recreated set", rep, q)
+    qs_b.close()
     store.close()
     print("scan_each ok", sorted(kernels))
 

@@ -422,7 +422,7 @@ def test_packed_store_file_written_without_a_gpu(tmp_path, alphabet, n_letters, 
     r = cli("makedb", "-i", fa, "-d", pk, "--packed", "--no-gpu", *(["--alphabet", "aa"] if alphabet else []))
     assert r.returncode == 0, r.stderr
     good = open(pk, "rb").read()
-    assert good[:8] == b"\x03\x02SMAFA\x00"
+    assert good[:8] == b"\x03\x02SMAFA\x01"  # version 3, kind 2, layout revision 1
     a, codes = smafa_amd.read_db(pk)
     assert a == alphabet and codes.tobytes() == s.tobytes()
     planes = struct.unpack_from("<I", good, 8 + 8)[0]
@@ -453,6 +453,9 @@ def test_packed_store_file_written_without_a_gpu(tmp_path, alphabet, n_letters, 
     for name, edit in cases.items():
         with pytest.raises(smafa_amd.SmafaError):
             smafa_amd.read_db(damaged(edit, name))
+    # a file of an earlier layout revision (16-bit column table) is refused by name, whatever its bytes would have decoded to
+    with pytest.raises(smafa_amd.SmafaError, match="older build.*re-run makedb --packed"):
+        smafa_amd.read_db(damaged(lambda b: b.__setitem__(7, 0), "old_revision"))
 
 
 @pytest.mark.parametrize("kind", ["fasta", "fasta_multiline_crlf", "fastq", "fastq_at_quality"])

@@ -252,6 +252,17 @@ def test_cluster_multi_one_process_equals_oracle(tmp_path, ndev):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-1000:]
     assert r.stdout == want.stdout
+    # every rank's handle lives on its own entry of --devices and its thread launched there (debug log of each rank): with
+    # more GPUs visible the entries spread over them, so a run where every replica silently lands on device 0 fails here
+    import re
+
+    devs = [d % smafa_amd.device_count() for d in range(ndev)]
+    rv = subprocess.run([smafa_amd._lib.CLI_PATH, "cluster", "-i", path, "-d", "4", "--devices", ",".join(map(str, devs)), "-v"],
+                        capture_output=True, text=True)
+    assert rv.returncode == 0 and rv.stdout == want.stdout
+    seen = sorted((int(a), int(b), int(c), int(d)) for a, b, c, d in re.findall(
+        r"rank (\d+) of \d+: handle on device (\d+), scan launches issued with device (-?\d+) current, (\d+) off", rv.stderr))
+    assert seen == [(r_, devs[r_], devs[r_], 0) for r_ in range(ndev)], (seen, rv.stderr[-1500:])
     out = str(tmp_path / "api.tsv")
     fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
     try:

@@ -111,3 +111,23 @@ def test_bad_record_after_good_ones(files, name):
     assert p.stdout != b""
     p = same(["cluster", "-i", files[name], "-d", "2"], 101)
     assert p.stdout != b""
+
+
+def test_no_subcommand_prints_help_and_succeeds():
+    """src/main.rs:52-56: `smafa` alone prints the help text (stdout) and returns Ok(())"""
+    p = product()
+    assert p.returncode == 0 and b"Usage: smafa" in p.stdout and b"makedb" in p.stdout and b"cluster" in p.stdout
+    for flag in ("-v", "-q", "--verbose", "--quiet"):  # the top-level flags alone are still "no subcommand"
+        p = product(flag)
+        assert p.returncode == 0 and b"Usage: smafa" in p.stdout
+
+
+@pytest.mark.parametrize("flag", ["-v", "-q", "--verbose", "--quiet"])
+def test_top_level_verbosity_flags_in_front_of_the_subcommand(files, flag):
+    """src/main.rs:67-68 declares -v/--verbose and -q/--quiet on the top-level command too: `smafa -q makedb ..` parses"""
+    p = product(flag, "makedb", "-i", files["ok.fa"], "-d", files["out"])
+    r = reference("makedb", "-i", files["ok.fa"], "-d", files["out"] + ".ref")
+    assert p.returncode == 0 and r.returncode == 0, p.stderr
+    assert open(files["out"], "rb").read() == open(files["out"] + ".ref", "rb").read()
+    p = product(flag, "count", "-i", files["ok.fa"])
+    assert p.returncode == 0 and p.stdout == reference("count", "-i", files["ok.fa"]).stdout

@@ -41,7 +41,8 @@ def test_group_rows_do_not_depend_on_the_number_of_handles(alphabet):
     everything = oracle.scan_codes(subj, qry[:64], L)  # every pair: the k-th modes without a bound, on 64 queries
     got = {}
     for ndev in (1, 2, 3):
-        g = smafa_amd.SubjectGroup(L, alphabet, devices=[0] * ndev)
+        devs = [d % smafa_amd.device_count() for d in range(ndev)]  # [0, 0, 0] on a one-GPU box, [0, 1, 2] on a node
+        g = smafa_amd.SubjectGroup(L, alphabet, devices=devs)
         assert len(g) == ndev
         g.push(subj[:25_000])
         g.push(subj[25_000:])
@@ -56,6 +57,10 @@ def test_group_rows_do_not_depend_on_the_number_of_handles(alphabet):
         small = g.scan(qry, max_divergence=D, cap=3)
         assert _rows(small).tobytes() == _rows(want).tobytes()
         got[ndev] = (fixed.tobytes(), best.tobytes(), k5.tobytes())
+        # every member lives on ITS entry of `devices`, and its worker thread launched there: smafa_db_info().device, the HIP
+        # device current on the launching thread, no launch off the handle's device (with more than one GPU visible the
+        # members spread over them: the first real `--devices 0,1,..` run cannot silently put every replica on device 0)
+        assert g.members() == [(d, d, 0) for d in devs], (devs, g.members())
         g.close()
     assert got[1] == got[2] == got[3]
 
