@@ -142,6 +142,8 @@ struct smafa_db {
     bool fold3 = true;        // scan_kernel's all-planes-but-the-last bound for launches whose bound starts above 32 (SMAFA_FOLD3=0)
     bool stream_nt = true;    // one-query-block launches of scan_lazy_kernel load their filter words non-temporally (SMAFA_STREAM_NT=0)
     uint32_t count_first_k = 3;  // smallest k whose loose-bound scans count first and append second (SMAFA_COUNT_FIRST_K)
+    uint32_t kth_sample_min_tiles = 4096;  // stores below this many wave tiles (1M subjects) count everything first (SMAFA_KTH_SAMPLE_MIN_TILES)
+    uint32_t kth_sample_div = 16;  // ... counting only the first 1/16 of the tiles, the rest counted and appended in one pass (SMAFA_KTH_SAMPLE=0: count everything first)
     // rows of a smafa_scan_hits call that ended in SMAFA_ERR_CAPACITY, kept for the caller's "grow and retry":
     // the retry with the same arguments against the same store is answered without scanning again
     std::vector<smafa_hit> retry_rows;
@@ -790,9 +792,21 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     // is sized for the appended volume, the caller's buffer only has to hold what is kept.
     // (k >= 2 with a loose bound counts first and appends only the final rows, straight into the caller's list.)
     const bool count_first = k_tight >= db->count_first_k && !prefilter_prunes(db, thr0);
+    // Counting first costs TWO passes over every pair (count, then append with the exact bounds).  On a big store the first
+    // one is cut to a SAMPLE — the first 1/16 of the tiles: the k-th smallest distance within any subset of the subjects is an
+    // upper bound of the k-th smallest over all of them — and the rest of the store is scanned ONCE, counting, tightening and
+    // appending to the scratch list from that bound on; the counts are then complete up to the k-th distance (the bound never
+    // dropped below it), so kth_from_counts_kernel gives the exact bounds, the sample's own tiles are scanned again with
+    // those fixed (appending), and filter_rows_kernel keeps what is within them: (1 + 1/16) passes instead of 2.
+    // Rows parked meanwhile: ~k x (segment / store seen before it) per segment, a few k per query (SMAFA_KTH_SAMPLE=0: two passes).
+    const uint32_t sample_tiles = (count_first && db->kth_sample_div && n_tiles >= db->kth_sample_min_tiles &&
+                                   n_tiles / db->kth_sample_div >= 1u &&
+                                   (uint64_t)k_tight * 4u <= (uint64_t)(n_tiles / db->kth_sample_div) * kWaveTile)
+                                      ? n_tiles / db->kth_sample_div : 0u;
     uint64_t scratch_rows = 0;
-    if (!count_first) {
-        scratch_rows = std::max<uint64_t>(2 * cap, std::min<uint64_t>((uint64_t)nq * 128u, 1ull << 27));
+    if (!count_first || sample_tiles) {
+        const uint64_t per_query = sample_tiles ? 16ull * k_tight + 128u : 128u;
+        scratch_rows = std::max<uint64_t>(2 * cap, std::min<uint64_t>((uint64_t)nq * per_query, 1ull << 27));
         int src = db->scratch.ensure(scratch_rows * sizeof(smafa_hit));
         if (src) return src;
     }
@@ -821,15 +835,37 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     // (cnt[q][dist]) and tightens, which yields the EXACT k-th distance of every query
     // (kth_from_counts_kernel); the second appends with those bounds fixed — exactly the rows that are kept.
     uint32_t begin = 0, len = kWgWaves;
-    while (!rc && begin < n_tiles) {
-        const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)begin + len, n_tiles);
+    const uint32_t count_end = sample_tiles ? sample_tiles : n_tiles;  // the tiles that are only counted
+    while (!rc && begin < count_end) {
+        const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)begin + len, count_end);
         rc = launch_tiles(db, qs, q_begin, q_end, begin, end, k_tight, thr0, count_first ? nullptr : d_scratch,
                           count_first ? 0 : scratch_rows, nullptr);
         begin = end;
         len = len > (1u << 28) ? len : len * 8;
     }
     if (rc) return rc;
-    if (count_first) {
+    if (sample_tiles) {
+        // bounds from the sample's counts (a query with fewer than k subjects in range so far keeps its bound)
+        hipLaunchKernelGGL(kth_from_counts_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream, qs->cnt.as<uint32_t>(),
+                           (uint32_t)cnt_stride, k_tight, qs->thr.as<uint32_t>(), q_begin, nq);
+        // the rest of the store, once: count, tighten, append to the scratch list — in segments growing 4x, so that the
+        // workgroups of one launch do not all start from the sample's bound
+        len = 3u * sample_tiles;
+        while (!rc && begin < n_tiles) {
+            const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)begin + len, n_tiles);
+            rc = launch_tiles(db, qs, q_begin, q_end, begin, end, k_tight, thr0, d_scratch, scratch_rows, nullptr);
+            begin = end;
+            len = len > (1u << 28) ? len : len * 4;
+        }
+        if (rc) return rc;
+        // every pair within the k-th distance has been counted once: the exact bounds; then the sample's own tiles with
+        // those bounds fixed, appending to the same list
+        hipLaunchKernelGGL(kth_from_counts_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream, qs->cnt.as<uint32_t>(),
+                           (uint32_t)cnt_stride, k_tight, qs->thr.as<uint32_t>(), q_begin, nq);
+        rc = launch_tiles(db, qs, q_begin, q_end, 0, sample_tiles, 0, thr0, d_scratch, scratch_rows, nullptr, true);
+        if (rc) return rc;
+        // (falls through to the filter pass below: rows within the exact bounds go to the caller's list)
+    } else if (count_first) {
         hipLaunchKernelGGL(kth_from_counts_kernel, dim3((nq + 255) / 256), dim3(256), 0, db->stream, qs->cnt.as<uint32_t>(),
                            (uint32_t)cnt_stride, k_tight, qs->thr.as<uint32_t>(), q_begin, nq);
         rc = launch_tiles(db, qs, q_begin, q_end, 0, n_tiles, 0, thr0, d_hits, cap, d_count, true);
@@ -1344,6 +1380,8 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     if (const char *f3 = getenv("SMAFA_FOLD3")) db->fold3 = atoi(f3) != 0;
     if (const char *sn = getenv("SMAFA_STREAM_NT")) db->stream_nt = atoi(sn) != 0;
     if (const char *cv = getenv("SMAFA_COUNT_FIRST_K")) db->count_first_k = (uint32_t)std::max(2, atoi(cv));
+    if (const char *ks = getenv("SMAFA_KTH_SAMPLE")) db->kth_sample_div = (uint32_t)std::max(0, atoi(ks));
+    if (const char *ks = getenv("SMAFA_KTH_SAMPLE_MIN_TILES")) db->kth_sample_min_tiles = (uint32_t)std::max(1, atoi(ks));
     if (const char *ov = getenv("SMAFA_WIDE_ONE")) db->wide_one = atoi(ov) != 0;
     if (const char *wv = getenv("SMAFA_WIDE_FROM")) db->wide_from = (uint32_t)std::max(3, atoi(wv));
     if (const char *zv = getenv("SMAFA_ZONE")) db->zone = std::min(2, std::max(0, atoi(zv)));

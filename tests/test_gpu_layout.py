@@ -366,7 +366,7 @@ def test_packed_store_cli_round_trip(tmp_path, with_n):
     assert run("makedb", "-i", sf, "-d", v2).returncode == 0
     r = run("makedb", "-i", sf, "-d", pk, "--packed")
     assert r.returncode == 0, r.stderr
-    assert open(pk, "rb").read(8) == b"\x03\x02SMAFA\x00"
+    assert open(pk, "rb").read(8) == b"\x03\x02SMAFA\x01"
     for flags in ([], ["--max-divergence", "5"], ["--max-num-hits", "4"], ["--max-num-hits", "5", "--limit-per-sequence", "1"]):
         want = oracle.run_cli("query", "-d", v2, "-q", qf, *flags)
         a, b = run("query", "-d", v2, "-q", qf, *flags), run("query", "-d", pk, "-q", qf, *flags)

@@ -191,6 +191,40 @@ def test_kth_bound_modes(k, max_div):
 
 
 @pytest.mark.parametrize("alphabet,n_letters", [(0, 4), (1, 20)])
+@pytest.mark.parametrize("div", [0, 2, 16])
+def test_kth_modes_counting_a_sample_first(alphabet, n_letters, div, monkeypatch):
+    """k >= 3 without a usable bound: the counting pass covers the first 1/div of the tiles only (an upper bound of every
+    query's k-th distance), the rest of the store is counted, tightened and appended in one pass, the exact bounds come from
+    the complete counts and the sample's tiles are scanned again with them (engine.hip scan_range).  Forced here on a small
+    store (SMAFA_KTH_SAMPLE_MIN_TILES; div 0 = everything counted first): rows == the oracle's, ties, dense spots, bounds."""
+    monkeypatch.setenv("SMAFA_KTH_SAMPLE", str(div))
+    monkeypatch.setenv("SMAFA_KTH_SAMPLE_MIN_TILES", "8")
+    monkeypatch.setenv("SMAFA_TWO_PHASE", "0")  # no near-hit ladder in front: every query takes the path under test
+    rng = np.random.default_rng(77 + alphabet)
+    L, n = 60, 30000
+    s = rng.integers(0, n_letters, size=(n, L), dtype=np.uint8)
+    s[200:260] = s[11]          # 61 copies: more ties than any k below
+    s[29000:29030] = s[12]      # a dense spot in the last tiles (not in any sample)
+    qs = [s[11], s[12], s[29999]]
+    for subs in (1, 3, 6, 10, 20, 35):
+        for base in (11, 12, 5000, 29500):
+            r = s[base].copy()
+            cols = rng.choice(L, size=subs, replace=False)
+            r[cols] = (r[cols] + 1 + rng.integers(0, n_letters - 1, size=subs)) % n_letters
+            qs.append(r)
+    qs += [rng.integers(0, n_letters, size=L, dtype=np.uint8) for _ in range(37)]
+    q = np.array(qs, dtype=np.uint8)
+    store = smafa_amd.SubjectStore(L, alphabet)
+    store.push(s)
+    for D in (None, 40, 25):
+        full = oracle.scan_codes(s, q, L if D is None else D)
+        for k in (3, 5, 40, 100):
+            got = store.scan(q, max_divergence=D, max_num_hits=k)
+            assert got.tobytes() == expected_with_k(full, k).tobytes(), (D, k)
+    store.close()
+
+
+@pytest.mark.parametrize("alphabet,n_letters", [(0, 4), (1, 20)])
 def test_near_hit_probe_boundaries(alphabet, n_letters):
     """k-th-distance modes with a loose or absent bound: a ladder of bounded scans (bounds 5, 12, then 30 — 16 for a 2-plane store — at L = 60) finishes
     the queries with at least k rows within a step's bound, the rest take the tightening path as a compacted batch;
