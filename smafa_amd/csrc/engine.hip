@@ -142,6 +142,7 @@ struct smafa_db {
     bool fold3 = true;        // scan_kernel's all-planes-but-the-last bound for launches whose bound starts above 32 (SMAFA_FOLD3=0)
     bool stream_nt = true;    // one-query-block launches of scan_lazy_kernel load their filter words non-temporally (SMAFA_STREAM_NT=0)
     uint32_t count_first_k = 3;  // smallest k whose loose-bound scans count first and append second (SMAFA_COUNT_FIRST_K)
+    bool kth_hist_seed = true;   // k >= 2: the seed bound from an LDS histogram over the first tiles (SMAFA_KTH_HIST_SEED=0: a counting launch)
     uint32_t kth_sample_min_tiles = 4096;  // stores below this many wave tiles (1M subjects) count everything first (SMAFA_KTH_SAMPLE_MIN_TILES)
     uint32_t kth_sample_div = 16;  // ... counting only the first 1/16 of the tiles, the rest counted and appended in one pass (SMAFA_KTH_SAMPLE=0: count everything first)
     // rows of a smafa_scan_hits call that ended in SMAFA_ERR_CAPACITY, kept for the caller's "grow and retry":
@@ -828,13 +829,23 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     // seed: k = 1 reduces each wave's minimum before its single atomicMin, so a whole workgroup tile is
     // cheap; the k >= 2 seed counts every pair in its histogram, so keep it to one wave tile
     const uint32_t seed_tiles = std::min<uint32_t>(k_tight == 1 ? kWgWaves : 1, n_tiles);
-    if (!rc) rc = launch_tiles(db, qs, q_begin, q_end, 0, seed_tiles, k_tight, thr0, nullptr, 0, nullptr);
-    if (!rc) rc = zero_cnt();  // the seed's subjects are counted again below
+    // k >= 2: the k-th smallest distance within the first (up to) 1024 subjects, from an LDS histogram per query
+    // (kth_seed_kernel: no global atomics; the counting launch it replaces put every pair of its tile through them)
+    const bool hist_seed = k_tight >= 2 && db->L < (uint32_t)kSeedBins && db->kth_hist_seed;
+    if (!rc && hist_seed) {
+        hipLaunchKernelGGL(kth_seed_kernel, dim3((nq + kSeedQueries - 1) / kSeedQueries), dim3(256), 0, db->stream,
+                           reinterpret_cast<const uint4 *>(db->d_planes), qs->qrec.as<uint32_t>(), db->QS, db->P, db->PQ, db->W,
+                           std::min<uint32_t>(kWgWaves, n_tiles), (uint32_t)db->n, q_begin, q_end, k_tight, thr0, qs->thr.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    } else {
+        if (!rc) rc = launch_tiles(db, qs, q_begin, q_end, 0, seed_tiles, k_tight, thr0, nullptr, 0, nullptr);
+        if (!rc) rc = zero_cnt();  // the seed's subjects are counted again below
+    }
     // k >= 2 with a bound the prefilter cannot use: a query appends every pair within its running k-th bound,
     // thousands of rows for k = 50 against unrelated subjects.  Two passes instead: the first only counts
     // (cnt[q][dist]) and tightens, which yields the EXACT k-th distance of every query
     // (kth_from_counts_kernel); the second appends with those bounds fixed — exactly the rows that are kept.
-    uint32_t begin = 0, len = kWgWaves;
+    uint32_t begin = 0, len = hist_seed ? 8u * kWgWaves : kWgWaves;  // (the histogram seed already stands for the first 4 tiles)
     const uint32_t count_end = sample_tiles ? sample_tiles : n_tiles;  // the tiles that are only counted
     while (!rc && begin < count_end) {
         const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)begin + len, count_end);
@@ -1380,6 +1391,7 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     if (const char *f3 = getenv("SMAFA_FOLD3")) db->fold3 = atoi(f3) != 0;
     if (const char *sn = getenv("SMAFA_STREAM_NT")) db->stream_nt = atoi(sn) != 0;
     if (const char *cv = getenv("SMAFA_COUNT_FIRST_K")) db->count_first_k = (uint32_t)std::max(2, atoi(cv));
+    if (const char *ks = getenv("SMAFA_KTH_HIST_SEED")) db->kth_hist_seed = atoi(ks) != 0;
     if (const char *ks = getenv("SMAFA_KTH_SAMPLE")) db->kth_sample_div = (uint32_t)std::max(0, atoi(ks));
     if (const char *ks = getenv("SMAFA_KTH_SAMPLE_MIN_TILES")) db->kth_sample_min_tiles = (uint32_t)std::max(1, atoi(ks));
     if (const char *ov = getenv("SMAFA_WIDE_ONE")) db->wide_one = atoi(ov) != 0;

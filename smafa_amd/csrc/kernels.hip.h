@@ -207,9 +207,21 @@ __device__ __forceinline__ void emit(const ScanArgs &a, RowStageT<ROWS> &rs, int
     } else if (a.k_tight >= 2) {
         uint32_t *c = a.cnt + (size_t)q * a.cnt_stride;
         atomicAdd(c + dist, 1u);
-        uint32_t seen = 0;
-        for (uint32_t t = 0; t <= dist; t++) seen += ld_relaxed(c + t);
-        if (seen >= a.k_tight) atomicMin(a.thr + q, dist);
+        // Can this pair lower the bound?  Only when it lies strictly below it — and most counted pairs sit ON the bound (the
+        // distance distribution rises steeply towards it): those are done.  The others add up the counts up to their own
+        // distance, eight independent loads in flight at a time (one dependent load per bin made a counted pair cost tens
+        // of microseconds of L2 latency: the k = 50 counting passes spent most of their time here).
+        if (dist < ld_relaxed(a.thr + q)) {
+            uint32_t seen = 0;
+            for (uint32_t t0 = 0; t0 <= dist; t0 += 8u) {
+                uint32_t v[8];
+#pragma unroll
+                for (uint32_t j = 0; j < 8u; j++) v[j] = ld_relaxed(c + min(t0 + j, dist));
+#pragma unroll
+                for (uint32_t j = 0; j < 8u; j++) seen += t0 + j <= dist ? v[j] : 0u;
+            }
+            if (seen >= a.k_tight) atomicMin(a.thr + q, dist);
+        }
     }
 }
 
@@ -1857,6 +1869,69 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(const uint4 *__restri
         if (a.hits) flush_rows(a, rs, parity);
     }
     finish_rows(a);
+}
+
+// Seed of the k >= 2 modes (max_num_hits = k, src/lib.rs:250-256): an upper bound of every query's k-th smallest distance from
+// the first wave tiles of the store (up to 4 = 1024 subjects) — the k-th smallest distance within ANY subset of the subjects
+// bounds the k-th smallest over all of them from above.  One workgroup = 4 waves = 4 tiles x kSeedQueries queries
+// (blockIdx.x = the chunk of queries): per query the waves compute the distances of their 256 subjects in full and count them
+// in an LDS histogram (no global atomic, no row), thread i then walks query i's histogram:
+// thr[q] = min(thr0, first d whose cumulative count reaches k); fewer than k subjects in range: thr0.
+// (The seed used to be a counting launch of the scan kernel over one tile with every bound at thr0: every pair of it went
+// through the global-atomic counting path — 9 ms per 10 000 queries at k = 5, profiles/r04_kth_dispatches.txt.)
+constexpr int kSeedQueries = 32;
+constexpr int kSeedBins = 256;  // sequences of up to 255 columns (longer ones keep the counting seed)
+__global__ __launch_bounds__(256) void kth_seed_kernel(const uint4 *__restrict__ planes, const uint32_t *__restrict__ qrec,
+                                                       uint32_t QS, uint32_t PS, uint32_t PQ, uint32_t W, uint32_t n_tiles,
+                                                       uint32_t n_subjects, uint32_t q_begin, uint32_t q_end, uint32_t k,
+                                                       uint32_t thr0, uint32_t *__restrict__ thr) {
+    __shared__ uint32_t hist[kSeedQueries][kSeedBins];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < (uint32_t)(kSeedQueries * kSeedBins); i += 256u) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    const uint32_t q0 = q_begin + blockIdx.x * kSeedQueries;
+    const uint32_t nq = min((uint32_t)kSeedQueries, q_end - q0);
+    const uint32_t pos = wave * kWaveTile + lane * 4u;
+    if (wave < n_tiles) {
+        const uint4 *t = planes + (size_t)wave * ((size_t)PS * W * 64) + lane;
+        for (uint32_t qi = 0; qi < nq; qi++) {
+            const uint32_t *rec = qrec + (size_t)(q0 + qi) * QS;
+            uint4 d = make_uint4(0, 0, 0, 0);
+            for (uint32_t w = 0; w < W; w++) {
+                uint32_t extra = 0;  // query bits in planes no subject has: a mismatch against every subject
+                for (uint32_t p = PS; p < PQ; p++) extra |= rec[qslot((int)PQ, (int)W, (int)p, (int)w)];
+                uint4 m = make_uint4(extra, extra, extra, extra);
+                for (uint32_t p = 0; p < PS; p++) {
+                    const uint4 v = t[(p * W + w) * 64];
+                    const uint32_t qv = rec[qslot((int)PQ, (int)W, (int)p, (int)w)];
+                    m.x = or_xor(m.x, v.x, qv);
+                    m.y = or_xor(m.y, v.y, qv);
+                    m.z = or_xor(m.z, v.z, qv);
+                    m.w = or_xor(m.w, v.w, qv);
+                }
+                d.x += __builtin_popcount(m.x);
+                d.y += __builtin_popcount(m.y);
+                d.z += __builtin_popcount(m.z);
+                d.w += __builtin_popcount(m.w);
+            }
+            if (pos + 0 < n_subjects && d.x <= thr0) atomicAdd(&hist[qi][d.x], 1u);
+            if (pos + 1 < n_subjects && d.y <= thr0) atomicAdd(&hist[qi][d.y], 1u);
+            if (pos + 2 < n_subjects && d.z <= thr0) atomicAdd(&hist[qi][d.z], 1u);
+            if (pos + 3 < n_subjects && d.w <= thr0) atomicAdd(&hist[qi][d.w], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < nq) {
+        uint32_t seen = 0, bound = thr0;
+        for (uint32_t d = 0; d <= thr0 && d < (uint32_t)kSeedBins; d++) {
+            seen += hist[tid][d];
+            if (seen >= k) {
+                bound = d;
+                break;
+            }
+        }
+        thr[q0 + tid] = bound;
+    }
 }
 
 // The literal get_distances seam (src/lib.rs:71-89): every subject's distance to ONE query, written at the subject's

@@ -191,13 +191,14 @@ def test_kth_bound_modes(k, max_div):
 
 
 @pytest.mark.parametrize("alphabet,n_letters", [(0, 4), (1, 20)])
-@pytest.mark.parametrize("div", [0, 2, 16])
-def test_kth_modes_counting_a_sample_first(alphabet, n_letters, div, monkeypatch):
+@pytest.mark.parametrize("div,hist_seed", [(0, 1), (2, 1), (16, 1), (16, 0)])
+def test_kth_modes_counting_a_sample_first(alphabet, n_letters, div, hist_seed, monkeypatch):
     """k >= 3 without a usable bound: the counting pass covers the first 1/div of the tiles only (an upper bound of every
     query's k-th distance), the rest of the store is counted, tightened and appended in one pass, the exact bounds come from
     the complete counts and the sample's tiles are scanned again with them (engine.hip scan_range).  Forced here on a small
     store (SMAFA_KTH_SAMPLE_MIN_TILES; div 0 = everything counted first): rows == the oracle's, ties, dense spots, bounds."""
     monkeypatch.setenv("SMAFA_KTH_SAMPLE", str(div))
+    monkeypatch.setenv("SMAFA_KTH_HIST_SEED", str(hist_seed))  # the seed bound: LDS histogram over the first tiles / a counting launch
     monkeypatch.setenv("SMAFA_KTH_SAMPLE_MIN_TILES", "8")
     monkeypatch.setenv("SMAFA_TWO_PHASE", "0")  # no near-hit ladder in front: every query takes the path under test
     rng = np.random.default_rng(77 + alphabet)

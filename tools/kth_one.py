@@ -1,0 +1,10 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, smafa_amd
+from smafa_amd import synth
+k = int(sys.argv[1])
+subj = synth.subjects(10_000_000, 60, 1, seed=1)
+q, _, _ = synth.queries(subj, 10_000, 1, seed=3, max_subs=10)
+store = smafa_amd.SubjectStore(60, 1); store.push(subj)
+store.scan(q, max_num_hits=k)
+store.scan(q, max_num_hits=k)
