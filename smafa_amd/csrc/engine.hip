@@ -144,7 +144,7 @@ struct smafa_db {
     uint32_t count_first_k = 3;  // smallest k whose loose-bound scans count first and append second (SMAFA_COUNT_FIRST_K)
     bool kth_hist_seed = true;   // k >= 2: the seed bound from an LDS histogram over the first tiles (SMAFA_KTH_HIST_SEED=0: a counting launch)
     uint32_t kth_sample_min_tiles = 4096;  // stores below this many wave tiles (1M subjects) count everything first (SMAFA_KTH_SAMPLE_MIN_TILES)
-    uint32_t kth_sample_div = 16;  // ... counting only the first 1/16 of the tiles, the rest counted and appended in one pass (SMAFA_KTH_SAMPLE=0: count everything first)
+    uint32_t kth_sample_div = 32;  // ... counting only the first 1/32 of the tiles, the rest counted and appended in one pass (SMAFA_KTH_SAMPLE=0: count everything first)
     // rows of a smafa_scan_hits call that ended in SMAFA_ERR_CAPACITY, kept for the caller's "grow and retry":
     // the retry with the same arguments against the same store is answered without scanning again
     std::vector<smafa_hit> retry_rows;
@@ -794,11 +794,12 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     // (k >= 2 with a loose bound counts first and appends only the final rows, straight into the caller's list.)
     const bool count_first = k_tight >= db->count_first_k && !prefilter_prunes(db, thr0);
     // Counting first costs TWO passes over every pair (count, then append with the exact bounds).  On a big store the first
-    // one is cut to a SAMPLE — the first 1/16 of the tiles: the k-th smallest distance within any subset of the subjects is an
+    // one is cut to a SAMPLE — the first 1/32 of the tiles: the k-th smallest distance within any subset of the subjects is an
     // upper bound of the k-th smallest over all of them — and the rest of the store is scanned ONCE, counting, tightening and
     // appending to the scratch list from that bound on; the counts are then complete up to the k-th distance (the bound never
     // dropped below it), so kth_from_counts_kernel gives the exact bounds, the sample's own tiles are scanned again with
-    // those fixed (appending), and filter_rows_kernel keeps what is within them: (1 + 1/16) passes instead of 2.
+    // those fixed (appending), and filter_rows_kernel keeps what is within them: (1 + 1/32) passes instead of 2
+    // (10 000 queries x 10M aa, k = 5 / 50, sample 1/8: 34 / 39 ms, 1/16: 30 / 35, 1/32: 28 / 35; profiles/r04_kth.txt).
     // Rows parked meanwhile: ~k x (segment / store seen before it) per segment, a few k per query (SMAFA_KTH_SAMPLE=0: two passes).
     const uint32_t sample_tiles = (count_first && db->kth_sample_div && n_tiles >= db->kth_sample_min_tiles &&
                                    n_tiles / db->kth_sample_div >= 1u &&
@@ -832,21 +833,45 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     // k >= 2: the k-th smallest distance within the first (up to) 1024 subjects, from an LDS histogram per query
     // (kth_seed_kernel: no global atomics; the counting launch it replaces put every pair of its tile through them)
     const bool hist_seed = k_tight >= 2 && db->L < (uint32_t)kSeedBins && db->kth_hist_seed;
-    if (!rc && hist_seed) {
-        hipLaunchKernelGGL(kth_seed_kernel, dim3((nq + kSeedQueries - 1) / kSeedQueries), dim3(256), 0, db->stream,
-                           reinterpret_cast<const uint4 *>(db->d_planes), qs->qrec.as<uint32_t>(), db->QS, db->P, db->PQ, db->W,
-                           std::min<uint32_t>(kWgWaves, n_tiles), (uint32_t)db->n, q_begin, q_end, k_tight, thr0, qs->thr.as<uint32_t>());
+    // ... and where a sample is counted first (sample_tiles), the same kernel counts the WHOLE sample: every pair of it, in LDS
+    // histograms that are added to cnt[q][d] — exactly what the counting launches would have counted, without their global
+    // atomics per pair and their growing segments (k = 50, 10 000 queries: 12 ms -> ~2 ms for a 1/32 sample)
+    const bool hist_sample = hist_seed && sample_tiles != 0;
+    auto launch_hist = [&](uint32_t tiles, uint32_t *d_cnt) {
+        const uint32_t n_chunks = (nq + kSeedQueries - 1) / kSeedQueries;
+        const uint32_t steps = (tiles + kWgWaves - 1) / kWgWaves;
+        // enough workgroups to fill the chip (8 per CU), never more tile groups than 4-tile steps
+        const uint32_t n_groups = d_cnt ? std::max(1u, std::min(steps, ((uint32_t)db->n_cu * 8u + n_chunks - 1) / n_chunks)) : 1u;
+        const dim3 grid(n_chunks * n_groups), block(256);
+        const uint4 *planes = reinterpret_cast<const uint4 *>(db->d_planes);
+        const uint32_t *qrec = qs->qrec.as<uint32_t>();
+        uint32_t *thr = qs->thr.as<uint32_t>();
+#define SMAFA_SEED(PS_, PQ_, W_)                                                                                              \
+    if (db->P == PS_ && db->PQ == PQ_ && db->W == W_) {                                                                       \
+        hipLaunchKernelGGL((kth_seed_kernel<PS_, PQ_, W_>), grid, block, 0, db->stream, planes, qrec, db->QS, db->P, db->PQ,    \
+                           db->W, tiles, (uint32_t)db->n, q_begin, q_end, n_chunks, n_groups, k_tight, thr0, thr, d_cnt,      \
+                           (uint32_t)cnt_stride);                                                                             \
+        return;                                                                                                               \
+    }
+        SMAFA_SEED(2, 3, 1) SMAFA_SEED(3, 3, 1) SMAFA_SEED(5, 5, 1) SMAFA_SEED(2, 3, 2) SMAFA_SEED(3, 3, 2) SMAFA_SEED(5, 5, 2)
+        SMAFA_SEED(2, 3, 3) SMAFA_SEED(3, 3, 3) SMAFA_SEED(5, 5, 3) SMAFA_SEED(2, 3, 4) SMAFA_SEED(3, 3, 4) SMAFA_SEED(5, 5, 4)
+#undef SMAFA_SEED
+        hipLaunchKernelGGL((kth_seed_kernel<0, 0, 0>), grid, block, 0, db->stream, planes, qrec, db->QS, db->P, db->PQ, db->W, tiles,
+                           (uint32_t)db->n, q_begin, q_end, n_chunks, n_groups, k_tight, thr0, thr, d_cnt, (uint32_t)cnt_stride);
+    };
+    if (!rc && hist_sample) {
+        launch_hist(sample_tiles, qs->cnt.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    } else if (!rc && hist_seed) {
+        launch_hist(std::min<uint32_t>(kWgWaves, n_tiles), nullptr);
         HIP_TRY(hipGetLastError());
     } else {
         if (!rc) rc = launch_tiles(db, qs, q_begin, q_end, 0, seed_tiles, k_tight, thr0, nullptr, 0, nullptr);
         if (!rc) rc = zero_cnt();  // the seed's subjects are counted again below
     }
-    // k >= 2 with a bound the prefilter cannot use: a query appends every pair within its running k-th bound,
-    // thousands of rows for k = 50 against unrelated subjects.  Two passes instead: the first only counts
-    // (cnt[q][dist]) and tightens, which yields the EXACT k-th distance of every query
-    // (kth_from_counts_kernel); the second appends with those bounds fixed — exactly the rows that are kept.
     uint32_t begin = 0, len = hist_seed ? 8u * kWgWaves : kWgWaves;  // (the histogram seed already stands for the first 4 tiles)
     const uint32_t count_end = sample_tiles ? sample_tiles : n_tiles;  // the tiles that are only counted
+    if (hist_sample) begin = count_end;  // counted already, every pair of them
     while (!rc && begin < count_end) {
         const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)begin + len, count_end);
         rc = launch_tiles(db, qs, q_begin, q_end, begin, end, k_tight, thr0, count_first ? nullptr : d_scratch,

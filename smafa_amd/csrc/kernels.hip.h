@@ -1871,38 +1871,62 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(const uint4 *__restri
     finish_rows(a);
 }
 
-// Seed of the k >= 2 modes (max_num_hits = k, src/lib.rs:250-256): an upper bound of every query's k-th smallest distance from
-// the first wave tiles of the store (up to 4 = 1024 subjects) — the k-th smallest distance within ANY subset of the subjects
-// bounds the k-th smallest over all of them from above.  One workgroup = 4 waves = 4 tiles x kSeedQueries queries
-// (blockIdx.x = the chunk of queries): per query the waves compute the distances of their 256 subjects in full and count them
-// in an LDS histogram (no global atomic, no row), thread i then walks query i's histogram:
-// thr[q] = min(thr0, first d whose cumulative count reaches k); fewer than k subjects in range: thr0.
-// (The seed used to be a counting launch of the scan kernel over one tile with every bound at thr0: every pair of it went
-// through the global-atomic counting path — 9 ms per 10 000 queries at k = 5, profiles/r04_kth_dispatches.txt.)
+// The k >= 2 modes (max_num_hits = k, src/lib.rs:250-256) start from an upper bound of every query's k-th smallest distance:
+// the k-th smallest distance within ANY subset of the subjects bounds the k-th smallest over all of them from above.  This
+// kernel counts the distances of wave tiles [0, n_tiles) — the seed (4 tiles) or the whole sample of the store (engine.hip
+// scan_range) — for EVERY pair, in LDS histograms: one workgroup = 4 waves x kSeedQueries queries (blockIdx.x % n_chunks = the
+// chunk of queries) walking its share of the tiles (blockIdx.x / n_chunks = tile group), a wave keeps one tile's planes in
+// registers per step and compares it with the chunk's queries in full; ds_add per pair, no global atomic, no row, no bound.
+//   cnt == NULL (one tile group):  thr[q] = min(thr0, first d whose cumulative count reaches k) straight from LDS;
+//   cnt != NULL:                   the histograms are added to cnt[q][d] (what the counting launches of the scan kernel would
+//                                  have counted, exactly) and kth_from_counts_kernel derives the bounds.
+// (Before: counting launches of the scan kernel with every bound at thr0 — each counted pair went through global atomics:
+// 9 ms per 10 000 queries for the first 256 subjects alone at k = 5, 12 ms for a 1/32 sample at k = 50; profiles/r04_kth.txt.)
+// PS_/PQ_/W_ = 0: run-time values (any shape); the common shapes are instantiated with compile-time values.
 constexpr int kSeedQueries = 32;
-constexpr int kSeedBins = 256;  // sequences of up to 255 columns (longer ones keep the counting seed)
+constexpr int kSeedBins = 256;  // sequences of up to 255 columns (longer ones keep the counting launches)
+template <int PS_, int PQ_, int W_>
 __global__ __launch_bounds__(256) void kth_seed_kernel(const uint4 *__restrict__ planes, const uint32_t *__restrict__ qrec,
-                                                       uint32_t QS, uint32_t PS, uint32_t PQ, uint32_t W, uint32_t n_tiles,
-                                                       uint32_t n_subjects, uint32_t q_begin, uint32_t q_end, uint32_t k,
-                                                       uint32_t thr0, uint32_t *__restrict__ thr) {
+                                                       uint32_t QS, uint32_t ps_rt, uint32_t pq_rt, uint32_t w_rt,
+                                                       uint32_t n_tiles, uint32_t n_subjects, uint32_t q_begin, uint32_t q_end,
+                                                       uint32_t n_chunks, uint32_t n_groups, uint32_t k, uint32_t thr0,
+                                                       uint32_t *__restrict__ thr, uint32_t *__restrict__ cnt, uint32_t cnt_stride) {
+    const uint32_t PS = PS_ ? (uint32_t)PS_ : ps_rt, PQ = PQ_ ? (uint32_t)PQ_ : pq_rt, W = W_ ? (uint32_t)W_ : w_rt;
+    constexpr int kMaxRegs = PS_ && W_ ? PS_ * W_ : 1;  // the tile in registers only for compile-time shapes
     __shared__ uint32_t hist[kSeedQueries][kSeedBins];
+    // Running bound per query: the k-th smallest distance among the pairs this workgroup has counted so far (recomputed after
+    // every 4-tile step).  Pairs above it cannot be among any k smallest, so they are not counted: after the first steps an
+    // ds_add is rare (counting EVERY pair, ~16 lanes per instruction hit the same bin: the 1/16 sample of the metric store
+    // took 6.4 ms that way, 4x the comparison itself).  The counts stay complete up to the bound, which never drops below
+    // this workgroup's own k-th distance, itself an upper bound of the sample's and of the store's.
+    __shared__ uint32_t bound_lds[kSeedQueries];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t i = tid; i < (uint32_t)(kSeedQueries * kSeedBins); i += 256u) (&hist[0][0])[i] = 0u;
+    if (tid < (uint32_t)kSeedQueries) bound_lds[tid] = thr0;
     __syncthreads();
-    const uint32_t q0 = q_begin + blockIdx.x * kSeedQueries;
+    const uint32_t chunk = blockIdx.x % n_chunks, group = blockIdx.x / n_chunks;
+    const uint32_t q0 = q_begin + chunk * kSeedQueries;
     const uint32_t nq = min((uint32_t)kSeedQueries, q_end - q0);
-    const uint32_t pos = wave * kWaveTile + lane * 4u;
-    if (wave < n_tiles) {
-        const uint4 *t = planes + (size_t)wave * ((size_t)PS * W * 64) + lane;
+    // tile groups are strided sets of 4-tile steps: step s of group g covers tiles 4 * (g + s * n_groups) .. + 3
+    for (uint32_t step = group; step * kWgWaves < n_tiles; step += n_groups) {  // (uniform trip count per workgroup)
+        const uint32_t tile = min(step * kWgWaves + wave, n_tiles - 1u);
+        const bool live = step * kWgWaves + wave < n_tiles;  // a wave past the range still meets the others at the barriers
+        const uint4 *t = planes + (size_t)tile * ((size_t)PS * W * 64) + lane;
+        uint4 s[kMaxRegs];
+        if (PS_ && W_) {
+#pragma unroll
+            for (int i = 0; i < kMaxRegs; i++) s[i] = t[i * 64];
+        }
+        const uint32_t pos = tile * kWaveTile + lane * 4u;
         for (uint32_t qi = 0; qi < nq; qi++) {
             const uint32_t *rec = qrec + (size_t)(q0 + qi) * QS;
             uint4 d = make_uint4(0, 0, 0, 0);
-            for (uint32_t w = 0; w < W; w++) {
+            for (uint32_t w = 0; w < W; w++) {  // (compile-time trip counts unroll by themselves; the run-time form cannot)
                 uint32_t extra = 0;  // query bits in planes no subject has: a mismatch against every subject
                 for (uint32_t p = PS; p < PQ; p++) extra |= rec[qslot((int)PQ, (int)W, (int)p, (int)w)];
                 uint4 m = make_uint4(extra, extra, extra, extra);
                 for (uint32_t p = 0; p < PS; p++) {
-                    const uint4 v = t[(p * W + w) * 64];
+                    const uint4 v = (PS_ && W_) ? s[(PS_ && W_) ? p * W + w : 0] : t[(p * W + w) * 64];
                     const uint32_t qv = rec[qslot((int)PQ, (int)W, (int)p, (int)w)];
                     m.x = or_xor(m.x, v.x, qv);
                     m.y = or_xor(m.y, v.y, qv);
@@ -1914,23 +1938,36 @@ __global__ __launch_bounds__(256) void kth_seed_kernel(const uint4 *__restrict__
                 d.z += __builtin_popcount(m.z);
                 d.w += __builtin_popcount(m.w);
             }
-            if (pos + 0 < n_subjects && d.x <= thr0) atomicAdd(&hist[qi][d.x], 1u);
-            if (pos + 1 < n_subjects && d.y <= thr0) atomicAdd(&hist[qi][d.y], 1u);
-            if (pos + 2 < n_subjects && d.z <= thr0) atomicAdd(&hist[qi][d.z], 1u);
-            if (pos + 3 < n_subjects && d.w <= thr0) atomicAdd(&hist[qi][d.w], 1u);
+            const uint32_t bnd = live ? bound_lds[qi] : 0u;
+            if (pos + 0 < n_subjects && d.x <= bnd && live) atomicAdd(&hist[qi][d.x], 1u);
+            if (pos + 1 < n_subjects && d.y <= bnd && live) atomicAdd(&hist[qi][d.y], 1u);
+            if (pos + 2 < n_subjects && d.z <= bnd && live) atomicAdd(&hist[qi][d.z], 1u);
+            if (pos + 3 < n_subjects && d.w <= bnd && live) atomicAdd(&hist[qi][d.w], 1u);
         }
-    }
-    __syncthreads();
-    if (tid < nq) {
-        uint32_t seen = 0, bound = thr0;
-        for (uint32_t d = 0; d <= thr0 && d < (uint32_t)kSeedBins; d++) {
-            seen += hist[tid][d];
-            if (seen >= k) {
-                bound = d;
-                break;
+        __syncthreads();
+        if (tid < nq) {  // the bound after this step: first d whose cumulative count reaches k
+            uint32_t seen = 0;
+            const uint32_t old = bound_lds[tid];
+            for (uint32_t d = 0; d <= old && d < (uint32_t)kSeedBins; d++) {
+                seen += hist[tid][d];
+                if (seen >= k) {
+                    bound_lds[tid] = d;
+                    break;
+                }
             }
         }
-        thr[q0 + tid] = bound;
+        __syncthreads();
+    }
+    if (cnt) {  // this group's share of the counts: complete up to its own final bound (bins above it hold what was counted
+                // while the bound was still looser — partial, and never needed: the sample's k-th distance is at most this bound)
+        const uint32_t bins = min(min(thr0 + 1u, cnt_stride), (uint32_t)kSeedBins);
+        for (uint32_t i = tid; i < nq * bins; i += 256u) {
+            const uint32_t qi = i / bins, d = i % bins;
+            const uint32_t v = hist[qi][d];
+            if (v && d <= bound_lds[qi]) atomicAdd(cnt + (size_t)(q0 + qi) * cnt_stride + d, v);
+        }
+    } else if (tid < nq) {
+        thr[q0 + tid] = bound_lds[tid];
     }
 }
 
