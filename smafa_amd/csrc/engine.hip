@@ -142,6 +142,7 @@ struct smafa_db {
     bool fold3 = true;        // scan_kernel's all-planes-but-the-last bound for launches whose bound starts above 32 (SMAFA_FOLD3=0)
     bool stream_nt = true;    // one-query-block launches of scan_lazy_kernel load their filter words non-temporally (SMAFA_STREAM_NT=0)
     uint32_t count_first_k = 3;  // smallest k whose loose-bound scans count first and append second (SMAFA_COUNT_FIRST_K)
+    bool lazy_fold = true;       // the filter-plane-resident kernel also at the bounds only its level 2 rejects at (SMAFA_LAZY_FOLD=0)
     bool kth_hist_seed = true;   // k >= 2: the seed bound from an LDS histogram over the first tiles (SMAFA_KTH_HIST_SEED=0: a counting launch)
     uint32_t kth_sample_min_tiles = 4096;  // stores below this many wave tiles (1M subjects) count everything first (SMAFA_KTH_SAMPLE_MIN_TILES)
     uint32_t kth_sample_div = 32;  // ... counting only the first 1/32 of the tiles, the rest counted and appended in one pass (SMAFA_KTH_SAMPLE=0: count everything first)
@@ -422,7 +423,9 @@ static int qset_fill(smafa_qset *qs, smafa_db *db, const uint8_t *query_codes, u
     qs->db = db;
     qs->nq = n_queries;
     qs->serial = g_qset_serial.fetch_add(1);
-    const uint64_t padded = std::max<uint64_t>((n_queries + 63) / 64 * 64, 64);
+    // whole 64-query chunks plus one: a chunk staged by scan_zone_kernel's LDS-DMA is always 64 records from wherever its
+    // query block starts (SMAFA_ZONE_FULL_DMA), so up to 63 records past the last query are read (zeros, never used)
+    const uint64_t padded = std::max<uint64_t>((n_queries + 63) / 64 * 64, 64) + 64;
     int rc = qs->qrec.ensure(padded * db->QS * sizeof(uint32_t));
     if (!rc) rc = qs->thr.ensure(padded * sizeof(uint32_t));
     if (rc) return rc;
@@ -442,10 +445,14 @@ static void note_kernel(const smafa_db *db, const char *fmt, ...) {
 template <int PS, int PQ, int W, int T>
 static void launch_lazy_t(const smafa_db *db, const uint32_t *d_qrec, const ScanArgs &a, uint32_t grid) {
     const bool seed = a.hits == nullptr && a.k_tight == 1;
-    note_kernel(db, "smafa::scan_lazy_kernel<%d, %d, %d, %d, %s>", PS, PQ, W, T, seed ? "true" : "false");
+    // two words per plane, bound 13..17: level 2 sums the filter plane's per-word popcounts (the OR-fold rejects nothing there)
+    const bool sumfold = W == 2 && !seed && a.thr0 > 12u && a.thr0 <= 17u;  // (fold_rejects sends bounds up to 14 here)
+    note_kernel(db, "smafa::scan_lazy_kernel<%d, %d, %d, %d, %s%s>", PS, PQ, W, T, seed ? "true" : "false", sumfold ? ", true" : "");
     const uint4 *planes = reinterpret_cast<const uint4 *>(db->d_planes);
     if (seed)
         hipLaunchKernelGGL((scan_lazy_kernel<PS, PQ, W, T, true>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
+    else if (W == 2 && sumfold)
+        hipLaunchKernelGGL((scan_lazy_kernel<PS, PQ, W, T, false, W == 2>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
     else
         hipLaunchKernelGGL((scan_lazy_kernel<PS, PQ, W, T, false>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
 }
@@ -521,9 +528,25 @@ static bool prefilter_prunes(const smafa_db *db, uint32_t bound) {
     return tail <= db->prune_p;
 }
 
+// Two words per plane: beyond the bounds level 1 prunes at, level 2 still rejects nearly every pair while the bound is well
+// below what unrelated sequences score on it — the OR of the two words' mismatch bits has ~3/4 of the second word's columns
+// set (+ half of the first word's columns that have no partner): bound <= half of that (L = 60: 12); then the per-word sums up
+// to 14 (SUMFOLD).  There the filter-plane-resident kernel — 16 subjects per lane, one plane streamed — beats the all-planes
+// one, which only ever uses its other planes for the pairs that pass: 10 000 queries x 10M aa, bound 8 / 9 / 10 / 12:
+// 8.7 / 9.5 / 8.9 / 9.6 -> 7.8 / 8.3 / 8.4 / 9.1 ms, bound 14: 12.2 -> 11.3 (tools/bound_probe.py, profiles/r04_bound_probe.txt).
+// SMAFA_LAZY_FOLD=0: off.
+static bool fold_rejects(const smafa_db *db, uint32_t bound) {
+    if (!db->lazy_fold || db->W != 2 || db->L < 56) return false;  // (measured at 60 columns; shorter second words: not claimed)
+    const uint32_t second = db->L - 32u;                                  // columns that have a partner in the other word
+    const uint32_t unrelated = (3u * second + 2u * (32u - second)) / 4u;  // expected popcount of the OR-fold (L = 60: 23)
+    // OR-fold up to 12, the per-word sums (SUMFOLD) at 13 and 14; from 15 on too many wave steps pass level 2 and fetch their
+    // tiles from L2 (bound 16: 18.1 ms against 13.8 for the all-planes kernel, whose tiles are resident)
+    return bound * 2u <= unrelated + 1u || bound <= 14u;
+}
+
 static bool use_lazy(const smafa_db *db, uint32_t thr0) {
     const bool wide = db->W >= db->wide_from || (db->W == 1 && db->wide_one);
-    return db->lazy && db->use_filter && db->W <= 4 && !wide && prefilter_prunes(db, thr0);
+    return db->lazy && db->use_filter && db->W <= 4 && !wide && (prefilter_prunes(db, thr0) || fold_rejects(db, thr0));
 }
 
 // More than four words per plane (L > 128): scan_wide_kernel under the same rule — its levels 1 and 2 are the lazy
@@ -1416,6 +1439,7 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     if (const char *f3 = getenv("SMAFA_FOLD3")) db->fold3 = atoi(f3) != 0;
     if (const char *sn = getenv("SMAFA_STREAM_NT")) db->stream_nt = atoi(sn) != 0;
     if (const char *cv = getenv("SMAFA_COUNT_FIRST_K")) db->count_first_k = (uint32_t)std::max(2, atoi(cv));
+    if (const char *lf = getenv("SMAFA_LAZY_FOLD")) db->lazy_fold = atoi(lf) != 0;
     if (const char *ks = getenv("SMAFA_KTH_HIST_SEED")) db->kth_hist_seed = atoi(ks) != 0;
     if (const char *ks = getenv("SMAFA_KTH_SAMPLE")) db->kth_sample_div = (uint32_t)std::max(0, atoi(ks));
     if (const char *ks = getenv("SMAFA_KTH_SAMPLE_MIN_TILES")) db->kth_sample_min_tiles = (uint32_t)std::max(1, atoi(ks));

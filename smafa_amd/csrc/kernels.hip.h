@@ -648,7 +648,10 @@ __host__ __device__ constexpr int lazy_min_waves(int ps, int w, int t) {
     return regs <= 64 ? 8 : regs <= 80 ? 6 : regs <= 96 ? 5 : regs <= 128 ? 4 : regs <= 168 ? 3 : 2;
 }
 
-template <int PS, int PQ, int W, int T, bool SEED>
+// SUMFOLD (two-word stores, launches whose bound is 13..17): level 2 is the filter plane's own distance — one popcount per
+// word chained through v_bcnt's accumulator — instead of the popcount of the words OR-ed together, which stops rejecting at 13
+// (see scan_kernel's FOLD 1; here with 16 subjects per lane and only the filter plane resident).
+template <int PS, int PQ, int W, int T, bool SEED, bool SUMFOLD = false>
 __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kernel(const uint4 *__restrict__ planes,
                                                                                   const uint32_t *__restrict__ qrec,
                                                                                   ScanArgs a) {
@@ -825,12 +828,25 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
                         uint32_t tsign[T];
 #pragma unroll
                         for (int t = 0; t < T; t++) {
-                            uint32_t m0, m1, m2, m3;
-                            fold(t, qw, m0, m1, m2, m3);
-                            tsign[t] = kPair ? ((__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu))
-                                             : (or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
-                                                    __builtin_popcount(m2) + nu) |
-                                                (__builtin_popcount(m3) + nu));
+                            if (SUMFOLD) {
+                                uint32_t t0 = nu, t1 = nu, t2 = nu, t3 = nu;
+#pragma unroll
+                                for (int w = 0; w < W; w++) {
+                                    const uint32_t qv = qw[qslot(PQ, W, FP, w)];
+                                    t0 += __builtin_popcount(f[t][w].x ^ qv);
+                                    t1 += __builtin_popcount(f[t][w].y ^ qv);
+                                    t2 += __builtin_popcount(f[t][w].z ^ qv);
+                                    t3 += __builtin_popcount(f[t][w].w ^ qv);
+                                }
+                                tsign[t] = or3(t0, t1, t2) | t3;
+                            } else {
+                                uint32_t m0, m1, m2, m3;
+                                fold(t, qw, m0, m1, m2, m3);
+                                tsign[t] = kPair ? ((__builtin_popcount(m0 & m1) + nu) | (__builtin_popcount(m2 & m3) + nu))
+                                                 : (or3(__builtin_popcount(m0) + nu, __builtin_popcount(m1) + nu,
+                                                        __builtin_popcount(m2) + nu) |
+                                                    (__builtin_popcount(m3) + nu));
+                            }
                             any |= tsign[t];
                         }
                         if (__ballot((int32_t)any < 0) != 0ull) {  // level 3, rare: fetch planes, compare exactly
@@ -941,6 +957,12 @@ constexpr int kFewTiles = SMAFA_FEW_TILES;  // wave tiles per wave in scan_zone_
 #define SMAFA_ZONE_VGPR_MASK 6  // word 0's zone masks also in vector registers for stores of up to this many vectors per tile
                                 // (nucleotides: -2.3 %; the amino-acid kernel has no register to spare: profiles/r03_zone_variants.txt)
 #endif
+#ifndef SMAFA_ZONE_OPAQUE_BUF
+#define SMAFA_ZONE_OPAQUE_BUF 1  // 1: the rare levels see the chunk parity through an opaque copy (their LDS addresses are formed there)
+#endif
+#ifndef SMAFA_ZONE_FULL_DMA
+#define SMAFA_ZONE_FULL_DMA 1  // 1: a staged chunk is always 64 whole records (the record array is padded by one chunk)
+#endif
 #ifndef SMAFA_ZONE_NLIVE
 #define SMAFA_ZONE_NLIVE 1  // 1: "tile slot t is inside the range" is ONE scalar (the number of live slots) instead of T lane masks
 #endif
@@ -1019,7 +1041,9 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
     // ~thr0, !FIXED keeps the chunk's per-query ~bound in nu_lds (read from thr at the top of the previous chunk, one
     // register per thread in flight, written at its end).
     auto dma = [&](int b, uint32_t qc) {  // lands at wave base + lane * 16 (lane-linear)
-        const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
+        // SMAFA_ZONE_FULL_DMA: always the whole chunk — the record array is padded by a chunk (engine.hip qset_fill), the heads
+        // of queries past the block are masked where they are read: no per-chunk count / compare / exec mask around the DMA
+        const uint32_t nqc = SMAFA_ZONE_FULL_DMA ? (uint32_t)kChunk : min((uint32_t)kChunk, q1 - qc);
         const uint4 *src = reinterpret_cast<const uint4 *>(qrec + (size_t)qc * RS);
 #pragma unroll
         for (int v = 0; v < NV; v++) {
@@ -1046,7 +1070,7 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
     };
     // exact comparison of one query against the 4 subjects this lane owns in `tile`, the tile's words streamed from
     // L2/HBM one 32-column word at a time (PS vectors live, not PS * W)
-    auto stream_compare = [&](uint32_t tile, const uint32_t(&qw)[RS], uint32_t q) {
+    auto stream_compare = [&](uint32_t tile, const uint32_t(&qw)[RS], uint32_t q, int parity) {
         const uint32_t U = ~qw[BS];
         const uint4 *src = planes + (size_t)tile * (PS * W * 64) + lane;
         uint32_t d[4] = {0u, 0u, 0u, 0u};
@@ -1073,7 +1097,7 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
         const uint32_t subj0 = tile * kWaveTile + lane * 4u;
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, rs, buf, q, subj0 + k, d[k]);
+            if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, rs, parity, q, subj0 + k, d[k]);
     };
 
     if (q0 < q1) {
@@ -1146,9 +1170,18 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
                         // for (6 % of the launch)
                         uint32_t tile_r = tile;
                         asm volatile("" : "+s"(tile_r));
+#if SMAFA_ZONE_OPAQUE_BUF
+                        // ... and the chunk parity likewise: the LDS addresses of the staged record and of the row stage
+                        // (five scalar instructions) were being formed in front of EVERY tile's survivor loop
+                        int buf_r = __builtin_amdgcn_readfirstlane(buf);
+                        asm volatile("" : "+s"(buf_r));
+#define SMAFA_ZONE_BUF buf_r
+#else
+#define SMAFA_ZONE_BUF buf
+#endif
                         // ---- level 2 (rare): the filter plane folded over all its words, words 1.. from L2/HBM
                         uint32_t qw[RS];
-                        read_record(&stage[buf][(uint32_t)i * RV], qw);
+                        read_record(&stage[SMAFA_ZONE_BUF][(uint32_t)i * RV], qw);
                         qw[BS] = nu;  // the staged record carries no bound
                         uint32_t m0 = ft.x ^ qw[0], m1 = ft.y ^ qw[0], m2 = ft.z ^ qw[0], m3 = ft.w ^ qw[0];
                         if (W > 1) {
@@ -1172,7 +1205,8 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
                         }
                         // ---- level 3: all planes, exactly
                         passes++;
-                        stream_compare(tile_r, qw, qc + (uint32_t)i);
+                        stream_compare(tile_r, qw, qc + (uint32_t)i, SMAFA_ZONE_BUF);
+#undef SMAFA_ZONE_BUF
                     }
                 };
                 static_assert(T <= 8, "tile slots are spelled out below");

@@ -5,11 +5,12 @@ import csv, glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 k = sys.argv[1] if len(sys.argv) > 1 else "5"
 env = dict(os.environ, TMPDIR="/tmp")
-if len(sys.argv) > 2:
+far = "far" in sys.argv[2:]
+if len(sys.argv) > 2 and sys.argv[2] != "far":
     env["SMAFA_KTH_SAMPLE"] = sys.argv[2]
-out = os.path.join(ROOT, "gpurun_out", "kth_trace_%s_%s" % (k, env.get("SMAFA_KTH_SAMPLE", "d")))
+out = os.path.join(ROOT, "gpurun_out", "kth_trace_%s_%s%s" % (k, env.get("SMAFA_KTH_SAMPLE", "d"), "_far" if far else ""))
 subprocess.run(["/opt/rocm/bin/rocprofv3", "--kernel-trace", "-d", out, "-o", "t", "--output-format", "csv", "--",
-                "python3", os.path.join(ROOT, "tools", "kth_one.py"), k], cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                "python3", os.path.join(ROOT, "tools", "kth_one.py"), k] + (["far"] if far else []), cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 rows = []
 for p in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
     rows += list(csv.DictReader(open(p, newline="")))
