@@ -142,6 +142,7 @@ struct smafa_db {
     bool fold3 = true;        // scan_kernel's all-planes-but-the-last bound for launches whose bound starts above 32 (SMAFA_FOLD3=0)
     bool stream_nt = true;    // one-query-block launches of scan_lazy_kernel load their filter words non-temporally (SMAFA_STREAM_NT=0)
     uint32_t count_first_k = 3;  // smallest k whose loose-bound scans count first and append second (SMAFA_COUNT_FIRST_K)
+    bool zone_direct = true;     // fixed-bound zone launches without LDS staging and barriers (SMAFA_ZONE_DIRECT=0: the staged form)
     bool lazy_fold = true;       // the filter-plane-resident kernel also at the bounds only its level 2 rejects at (SMAFA_LAZY_FOLD=0)
     bool kth_hist_seed = true;   // k >= 2: the seed bound from an LDS histogram over the first tiles (SMAFA_KTH_HIST_SEED=0: a counting launch)
     uint32_t kth_sample_min_tiles = 4096;  // stores below this many wave tiles (1M subjects) count everything first (SMAFA_KTH_SAMPLE_MIN_TILES)
@@ -447,7 +448,7 @@ static void launch_lazy_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
     const bool seed = a.hits == nullptr && a.k_tight == 1;
     // two words per plane, bound 13..17: level 2 sums the filter plane's per-word popcounts (the OR-fold rejects nothing there)
     const bool sumfold = W == 2 && !seed && a.thr0 > 12u && a.thr0 <= 17u;  // (fold_rejects sends bounds up to 14 here)
-    note_kernel(db, "smafa::scan_lazy_kernel<%d, %d, %d, %d, %s%s>", PS, PQ, W, T, seed ? "true" : "false", sumfold ? ", true" : "");
+    note_kernel(db, "smafa::scan_lazy_kernel<%d, %d, %d, %d, %s, %s>", PS, PQ, W, T, seed ? "true" : "false", sumfold ? "true" : "false");
     const uint4 *planes = reinterpret_cast<const uint4 *>(db->d_planes);
     if (seed)
         hipLaunchKernelGGL((scan_lazy_kernel<PS, PQ, W, T, true>), dim3(grid), dim3(256), 0, db->stream, planes, d_qrec, a);
@@ -467,8 +468,11 @@ static void launch_zone_t(const smafa_db *db, const uint32_t *d_qrec, const Scan
         return;
     }
     const bool fixed = a.thr == nullptr;  // one bound for every query: LDS-DMA staging, scalar bound
-    note_kernel(db, "smafa::scan_zone_kernel<%d, %d, %d, %s>", PS, PQ, W, fixed ? "true" : "false");
-    if (fixed)
+    const bool direct = fixed && db->zone_direct && a.hits != nullptr;  // ... or no staging at all (SMAFA_ZONE_DIRECT)
+    note_kernel(db, "smafa::scan_zone_kernel<%d, %d, %d, %s, %s>", PS, PQ, W, fixed ? "true" : "false", direct ? "true" : "false");
+    if (direct)
+        hipLaunchKernelGGL((scan_zone_kernel<PS, PQ, W, true, true>), dim3(grid), dim3(kZoneWgWaves * 64), 0, db->stream, planes, d_qrec, a);
+    else if (fixed)
         hipLaunchKernelGGL((scan_zone_kernel<PS, PQ, W, true>), dim3(grid), dim3(kZoneWgWaves * 64), 0, db->stream, planes, d_qrec, a);
     else
         hipLaunchKernelGGL((scan_zone_kernel<PS, PQ, W, false>), dim3(grid), dim3(kZoneWgWaves * 64), 0, db->stream, planes, d_qrec, a);
@@ -1439,6 +1443,7 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     if (const char *f3 = getenv("SMAFA_FOLD3")) db->fold3 = atoi(f3) != 0;
     if (const char *sn = getenv("SMAFA_STREAM_NT")) db->stream_nt = atoi(sn) != 0;
     if (const char *cv = getenv("SMAFA_COUNT_FIRST_K")) db->count_first_k = (uint32_t)std::max(2, atoi(cv));
+    if (const char *zd = getenv("SMAFA_ZONE_DIRECT")) db->zone_direct = atoi(zd) != 0;
     if (const char *lf = getenv("SMAFA_LAZY_FOLD")) db->lazy_fold = atoi(lf) != 0;
     if (const char *ks = getenv("SMAFA_KTH_HIST_SEED")) db->kth_hist_seed = atoi(ks) != 0;
     if (const char *ks = getenv("SMAFA_KTH_SAMPLE")) db->kth_sample_div = (uint32_t)std::max(0, atoi(ks));

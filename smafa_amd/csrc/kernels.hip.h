@@ -926,6 +926,22 @@ __global__ __launch_bounds__(256, lazy_min_waves(PS, W, T)) void scan_lazy_kerne
 // Where the prefilter stops paying for a wave (dense neighbourhoods) it falls back to the plain comparison with one
 // tile's planes in registers, exactly like scan_lazy_kernel.
 // ---------------------------------------------------------------------------------------------
+// A qualifying pair appended straight to the caller's list: the lanes that got here together take consecutive rows with ONE
+// global atomic (v_mbcnt ranks them).  For kernels whose waves never meet at a barrier (scan_zone_kernel<.., DIRECT>): rows
+// are rare there (a fixed tight bound on a sorted store), so the workgroup-level LDS stage has nothing to batch.
+__device__ __forceinline__ void emit_direct(const ScanArgs &a, uint32_t q, uint32_t pos, uint32_t dist) {
+    smafa_hit h;
+    h.query = q;
+    h.subject = a.order[pos];
+    h.dist = dist;
+    const unsigned long long together = __ballot(1);
+    const int first = __builtin_ctzll(together);
+    unsigned long long g = 0;
+    if ((int)__lane_id() == first) g = atomicAdd(a.count, (unsigned long long)__builtin_popcountll(together));
+    g = shfl_u64(g, first) + lanes_below(together);
+    if (g < a.cap) a.hits[g] = h;
+}
+
 #ifndef SMAFA_ZONE_TILES
 #define SMAFA_ZONE_TILES 4
 #endif
@@ -972,9 +988,15 @@ __host__ __device__ constexpr int zone_min_waves(int ps, int w) { return ps * w 
 // LDS-DMA (global_load_lds_dwordx4: no register hop — the prefetch registers of the other form were being spilled
 // across every chunk, 1.2 GB of scratch writes per launch), nothing has to be merged into the records, and ~bound is a
 // scalar.  !FIXED (per-query bounds that tighten while the scan runs): register prefetch, ~bound merged at fetch time.
-template <int PS, int PQ, int W, bool FIXED>
+// DIRECT (FIXED only): no LDS staging and no barrier at all.  Lane i loads the head of query i of the chunk straight from
+// the record array (8 bytes, the next chunk's one chunk ahead), the rare levels read the record through scalar loads, rows go
+// straight to the list (emit_direct).  The staged form's waves wait for each other at a barrier per chunk, and the compiler
+// guards every LDS read of a staged record with s_waitcnt vmcnt(0) — it cannot tell the buffer being read from the one the
+// next chunk's LDS-DMA is landing in — so each wave stalled on its own prefetch once per chunk.
+template <int PS, int PQ, int W, bool FIXED, bool DIRECT = false>
 __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan_zone_kernel(const uint4 *__restrict__ planes,
                                                            const uint32_t *__restrict__ qrec, ScanArgs a) {
+    static_assert(FIXED || !DIRECT, "per-query bounds keep the staged form");
     constexpr int T = kZoneTiles;
     constexpr int RS = qrec_stride(PQ, W);
     constexpr int RV = RS / 4;
@@ -1097,25 +1119,43 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
         const uint32_t subj0 = tile * kWaveTile + lane * 4u;
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, rs, parity, q, subj0 + k, d[k]);
+            if (d[k] <= U && subj0 + k < a.n_subjects) {
+                if (DIRECT) emit_direct(a, q, subj0 + k, d[k]);
+                else emit(a, rs, parity, q, subj0 + k, d[k]);
+            }
     };
+    // DIRECT: the head [f0 f1] of this lane's query of a chunk, straight from the record array (records are padded by a
+    // chunk: lanes past the block read zeros or a neighbour's head, and are masked where the head is used)
+    auto load_head = [&](uint32_t qc) -> uint2 {
+        return *reinterpret_cast<const uint2 *>(qrec + (size_t)(qc + lane) * RS);
+    };
+    uint2 head_next = make_uint2(0u, 0u);
 
-    if (q0 < q1) {
-        dma(0, q0);
-        if (!FIXED && tid < (uint32_t)kChunk) nu_lds[0][tid] = load_bound(q0);
+    if (!DIRECT) {
+        if (q0 < q1) {
+            dma(0, q0);
+            if (!FIXED && tid < (uint32_t)kChunk) nu_lds[0][tid] = load_bound(q0);
+        }
+        // The DMA'd chunk is published by the barrier: every wave waits for its own global_load_lds first (the barrier's
+        // fence does not have to: gfx950's s_barrier has no implicit vmcnt wait).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else if (q0 < q1) {
+        head_next = load_head(q0);
     }
-    // The DMA'd chunk is published by the barrier: every wave waits for its own global_load_lds first (the barrier's
-    // fence does not have to: gfx950's s_barrier has no implicit vmcnt wait).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     bool filter_on = a.use_filter != 0;
     uint32_t chunk_no = 0;
     for (uint32_t qc = q0; qc < q1; qc += kChunk, buf ^= 1, chunk_no++) {
         const uint32_t nqc = min((uint32_t)kChunk, q1 - qc);
         const bool more = qc + kChunk < q1;
+        const uint2 head_cur = head_next;
         if (more) {  // in flight while this chunk is computed
-            dma(buf ^ 1, qc + kChunk);  // every wave passed the barrier that ended the last use of that buffer
-            if (!FIXED) nu_next = load_bound(qc + kChunk);
+            if (DIRECT) {
+                head_next = load_head(qc + kChunk);
+            } else {
+                dma(buf ^ 1, qc + kChunk);  // every wave passed the barrier that ended the last use of that buffer
+                if (!FIXED) nu_next = load_bound(qc + kChunk);
+            }
         }
         if (active) {
             const bool probe = a.use_filter && (filter_on || (chunk_no & 15u) == 0);
@@ -1123,7 +1163,8 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
                 uint32_t passes = 0;  // (query, tile) pairs of this chunk that needed the exact comparison
                 // ---- zone level: lane i holds [f0 f1 ~bound ..] of query i of the chunk
                 uint4 head = make_uint4(0u, 0u, 0u, 0u);  // lanes past the chunk: ~bound = 0 never passes
-                if (lane < nqc) head = stage[buf][lane * RV];
+                if (DIRECT) head.x = head_cur.x, head.y = head_cur.y;
+                else if (lane < nqc) head = stage[buf][lane * RV];
                 const uint32_t hq0 = head.x, hq1 = W > 1 ? head.y : 0u;
                 const uint32_t hnu = lane < nqc ? (FIXED ? nu0 : nu_lds[buf][lane]) : 0u;
                 // (opaque copy: the comparisons against it are redone per chunk — one s_cmp each — instead of being hoisted
@@ -1181,7 +1222,8 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
 #endif
                         // ---- level 2 (rare): the filter plane folded over all its words, words 1.. from L2/HBM
                         uint32_t qw[RS];
-                        read_record(&stage[SMAFA_ZONE_BUF][(uint32_t)i * RV], qw);
+                        if (DIRECT) read_record(reinterpret_cast<const uint4 *>(qrec + (size_t)(qc + (uint32_t)i) * RS), qw);
+                        else read_record(&stage[SMAFA_ZONE_BUF][(uint32_t)i * RV], qw);
                         qw[BS] = nu;  // the staged record carries no bound
                         uint32_t m0 = ft.x ^ qw[0], m1 = ft.y ^ qw[0], m2 = ft.z ^ qw[0], m3 = ft.w ^ qw[0];
                         if (W > 1) {
@@ -1232,7 +1274,7 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
                     const uint4 *src = planes + (size_t)(SMAFA_ZONE_NLIVE ? tile_d : tile) * (PS * W * 64) + lane;
 #pragma unroll
                     for (int i = 0; i < PS * W; i++) s[i] = src[i * 64];
-                    const uint4 *rec = &stage[buf][0];
+                    const uint4 *rec = DIRECT ? reinterpret_cast<const uint4 *>(qrec + (size_t)qc * RS) : &stage[buf][0];
                     for (uint32_t i = 0; i < nqc; i++, rec += RV) {
                         uint32_t qw[RS];
                         read_record(rec, qw);
@@ -1261,16 +1303,21 @@ __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan
                         const uint32_t subj0 = tile * kWaveTile + lane * 4u;
 #pragma unroll
                         for (int k = 0; k < 4; k++)
-                            if (d[k] <= U && subj0 + k < a.n_subjects) emit(a, rs, buf, qc + i, subj0 + k, d[k]);
+                            if (d[k] <= U && subj0 + k < a.n_subjects) {
+                                if (DIRECT) emit_direct(a, qc + i, subj0 + k, d[k]);
+                                else emit(a, rs, buf, qc + i, subj0 + k, d[k]);
+                            }
                     }
                 }
                 load_filter();  // not kept across the walk (its registers hold the tile meanwhile): fetched again
             }
         }
-        if (more && !FIXED && tid < (uint32_t)kChunk) nu_lds[buf ^ 1][tid] = nu_next;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next chunk's DMA has landed
-        __syncthreads();
-        if (a.hits) flush_rows(a, rs, buf);
+        if (!DIRECT) {
+            if (more && !FIXED && tid < (uint32_t)kChunk) nu_lds[buf ^ 1][tid] = nu_next;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next chunk's DMA has landed
+            __syncthreads();
+            if (a.hits) flush_rows(a, rs, buf);
+        }
     }
     finish_rows(a);
 }

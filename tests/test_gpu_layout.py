@@ -62,7 +62,7 @@ def expected_with_k(all_hits, k):
 @pytest.fixture
 def zone_env():
     """SMAFA_ZONE / SMAFA_SORT are read when a handle is created"""
-    old = {k: os.environ.get(k) for k in ("SMAFA_ZONE", "SMAFA_SORT")}
+    old = {k: os.environ.get(k) for k in ("SMAFA_ZONE", "SMAFA_SORT", "SMAFA_ZONE_DIRECT")}
     yield os.environ
     for k, v in old.items():
         if v is None:
@@ -79,6 +79,7 @@ def test_skewed_columns_sorted_store_all_modes(zone_env, alphabet, n_letters, L,
     layout, on the order of positions, or on the zone level (off / automatic / forced)"""
     zone_env["SMAFA_ZONE"] = zone
     rng = np.random.default_rng(L * 31 + n_letters + 7 * int(zone))
+    zone_env["SMAFA_ZONE_DIRECT"] = str(int(rng.integers(0, 2)))  # both forms of the fixed-bound zone kernel across the cases
     n = 9000
     s = skewed_store(rng, n, L, n_letters, families=40 if L >= 60 else 0)
     q = queries_from(rng, s, 150, n_letters, 7)
@@ -96,8 +97,11 @@ def test_skewed_columns_sorted_store_all_modes(zone_env, alphabet, n_letters, L,
     store.close()
 
 
-def test_zone_kernel_is_the_one_that_runs_when_forced(zone_env):
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_zone_kernel_is_the_one_that_runs_when_forced(zone_env, direct):
+    """... in its unstaged form (fixed bound: heads straight from the record array, no barrier) and in the staged one"""
     zone_env["SMAFA_ZONE"] = "2"
+    zone_env["SMAFA_ZONE_DIRECT"] = direct
     rng = np.random.default_rng(5)
     s = rng.integers(0, 20, size=(20000, 60), dtype=np.uint8)
     q = queries_from(rng, s, 300, 20, 8)
@@ -105,7 +109,7 @@ def test_zone_kernel_is_the_one_that_runs_when_forced(zone_env):
     store.push(s)
     got = store.scan(q, max_divergence=5)
     assert got.tobytes() == oracle.scan_codes(s, q, 5).tobytes()
-    assert store.last_scan_kernel() == "smafa::scan_zone_kernel<5, 5, 2, true>"
+    assert store.last_scan_kernel() == "smafa::scan_zone_kernel<5, 5, 2, true, %s>" % ("true" if direct == "1" else "false")
     for few in (1, 3, 64):  # a handful of queries per pass: tiles fetched on demand
         one = store.scan(q[:few], max_divergence=5)
         assert one.tobytes() == oracle.scan_codes(s, q[:few], 5).tobytes()
@@ -115,7 +119,7 @@ def test_zone_kernel_is_the_one_that_runs_when_forced(zone_env):
     store = smafa_amd.SubjectStore(60, 1)
     store.push(s)
     assert store.scan(q, max_divergence=5).tobytes() == got.tobytes()
-    assert store.last_scan_kernel() == "smafa::scan_lazy_kernel<5, 5, 2, 4, false>"
+    assert store.last_scan_kernel() == "smafa::scan_lazy_kernel<5, 5, 2, 4, false, false>"
     store.close()
 
 
