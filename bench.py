@@ -18,7 +18,7 @@ of fixed size.  Besides the contract's fields the line carries (N = 1 only, all 
 
   roofline           dominant kernel of the timed launch, live HIP-event time; VALU-bound: frac = VALU lane-ops/s over the
                      chip's nominal issue peak, instruction count from the committed rocprofv3 counter record of this same
-                     command (profiles/r03_pmc.json, tools/collect_pmc.py; `insts_source_is_this_build` says whether the
+                     command (profiles/r04_pmc.json, tools/collect_pmc.py; `insts_source_is_this_build` says whether the
                      record belongs to the binary being timed)
   stream             ONE query per store pass (north_star's "each query is broadcast against all subjects"): the HBM-bound
                      form, on a plane LARGER than the 256 MB Infinity Cache (the 50M-row store's 400 MB filter plane),
@@ -167,7 +167,7 @@ def pmc_records():
 
 
 def pmc_lookup(cfg: dict, kernel: str):
-    """the committed counter record of this workload and kernel (first file that has one wins: r03, then r02)"""
+    """the committed counter record of this workload and kernel (first file that has one wins: r04, r03, r02)"""
     def norm(c):
         return (c.get("db_rows"), c.get("seq_len"), c.get("queries"), c.get("max_div"), c.get("alphabet"),
                 c.get("store", "uniform"), float(c.get("n_frac", 0.0)), int(c.get("prefilter", 1)), c.get("mode", "scan"),

@@ -215,7 +215,7 @@ def cluster_main(a, out, prof):
 
     from smafa_amd import synth
 
-    fasta = "/tmp/r03_cluster_5M.faa"
+    fasta = "/tmp/r04_cluster_5M.faa"
     if not os.path.exists(fasta):
         recs = synth.cluster_records(100_000, 50, 60, 1, seed=4, max_subs=4)
         letters = np.array([ord("A") + i for i in range(26)] + [ord("*"), ord("-")], dtype=np.uint8)

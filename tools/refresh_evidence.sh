@@ -1,9 +1,9 @@
 #!/bin/bash
 # On the GPU box, after ANY change to kernels.hip.h / engine.hip (the build id changes): collect the counter records of
 # every workload bench.py looks up (tools/collect_pmc.py: rocprofv3 --pmc passes of the same bench command, program directly
-# after `--`), assemble profiles/r03_pmc.json, take the bench line of record with it in place, and leave everything under
+# after `--`), assemble profiles/r04_pmc.json, take the bench line of record with it in place, and leave everything under
 # gpurun_out/evidence/ in the names profiles/ uses (copy them over afterwards).  Three parts, in one call (about six minutes)
-# or in several (then copy gpurun_out/evidence/part_<x>.json to profiles/r03_pmc_part_<x>.json in between):
+# or in several (then copy gpurun_out/evidence/part_<x>.json to profiles/r04_pmc_part_<x>.json in between):
 #   gpurun --timeout 1150 -- 'cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && tools/refresh_evidence.sh a && tools/refresh_evidence.sh b && tools/refresh_evidence.sh c'
 cd "$(dirname "$0")/.."
 E=gpurun_out/evidence
@@ -22,9 +22,11 @@ if [ "$part" = a ]; then
   collect ev_d14 $light -- --max-div 14 || exit 1
   collect ev_d24 $light -- --max-div 24 || exit 1
   collect ev_best $light --steps 4 -- --mode besthit || exit 1
+  collect ev_k5 $light --steps 4 -- --mode kth --kth-k 5 || exit 1
+  collect ev_k50 $light --steps 4 -- --mode kth --kth-k 50 || exit 1
   python3 - <<'PY'
 import json
-tags = ("ev_aa", "ev_unf", "ev_d8", "ev_d14", "ev_d24", "ev_best")
+tags = ("ev_aa", "ev_unf", "ev_d8", "ev_d14", "ev_d24", "ev_best", "ev_k5", "ev_k50")
 json.dump({"records": [json.load(open("gpurun_out/%s/pmc_record.json" % t)) for t in tags]}, open("gpurun_out/evidence/part_a.json", "w"), indent=1)
 PY
 elif [ "$part" = b ]; then
@@ -45,25 +47,29 @@ else  # part c: the cluster record, the assembled file, the bench line of record
 import csv, glob, json, os, shutil
 E = "gpurun_out/evidence"
 recs = []
-for part in ("a", "b"):  # the parts travel as profiles/r03_pmc_part_<x>.json (copied there from gpurun_out/evidence/ between calls)
-    for path in ("gpurun_out/evidence/part_%s.json" % part, "profiles/r03_pmc_part_%s.json" % part):
+for part in ("a", "b"):  # the parts travel as profiles/r04_pmc_part_<x>.json (copied there from gpurun_out/evidence/ between calls)
+    for path in ("gpurun_out/evidence/part_%s.json" % part, "profiles/r04_pmc_part_%s.json" % part):
         if os.path.exists(path):
             recs += json.load(open(path))["records"]
             break
 recs.append(json.load(open("gpurun_out/ev_cluster/pmc_record.json")))
-json.dump({"records": recs}, open(E + "/r03_pmc.json", "w"), indent=1)
-shutil.copy(E + "/r03_pmc.json", "profiles/r03_pmc.json")  # on the box: the bench line below looks it up
+json.dump({"records": recs}, open(E + "/r04_pmc.json", "w"), indent=1)
+shutil.copy(E + "/r04_pmc.json", "profiles/r04_pmc.json")  # on the box: the bench line below looks it up
 PY
-  python3 bench.py --steps 20 --warmup 5 > $E/r03_bench.json 2> $E/bench.err || exit 1
+  python3 tools/stream_pmc.py > $E/stream_pmc.log 2>&1 && cp gpurun_out/r04_stream_pmc.json $E/r04_stream_pmc.json && cp $E/r04_stream_pmc.json profiles/r04_stream_pmc.json
+  python3 bench.py --steps 20 --warmup 5 --full-record $E/r04_bench_full.json > $E/r04_bench.json 2> $E/bench.err || exit 1
+  wc -c $E/r04_bench.json
   python3 - <<'PY'
 import json
-d = json.load(open("gpurun_out/evidence/r03_bench.json"))
+d = json.load(open("gpurun_out/evidence/r04_bench_full.json"))
 r = d["roofline"]
 print("headline %.3f ms/step %.3f M q/s frac %s this build %s verified %s run %s s" % (d["ms_per_step"], d["value"] / 1e6, r.get("frac"), r.get("insts_source_is_this_build"), d["verified"], d["run_s"]))
 for k in ("unfiltered", "besthit_unbounded", "related"):
     if d.get(k): print(k, d[k].get("kernel_ms"), d[k]["roofline"].get("frac"))
 for x in d.get("loose_bounds") or []: print("bound", x["max_divergence"], x["kernel_ms"], x["roofline"].get("frac"))
 for k, v in (d.get("configs") or {}).items(): print(k, v.get("kernel_ms"), (v.get("roofline") or {}).get("frac"), v.get("verified"))
+for k, v in (d.get("kth") or {}).items():
+    if isinstance(v, dict): print(k, v.get("wall_ms"), v.get("kernel_ms"), v["roofline"].get("frac"), v.get("verified"))
 print("stream", d["stream"]["roofline"])
 PY
 fi
@@ -84,10 +90,10 @@ def only_scan(src_glob, dst):
     if head:
         with open(dst, "w", newline="") as f:
             w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC); w.writerow(head); w.writerows(rows)
-for stats in glob.glob("gpurun_out/ev_aa/stats/**/*kernel_stats.csv", recursive=True): shutil.copy(stats, E + "/r03_kernel_stats.csv")
-only_scan("gpurun_out/ev_aa/stats/**/*kernel_trace.csv", E + "/r03_kernel_trace_scan.csv")
+for stats in glob.glob("gpurun_out/ev_aa/stats/**/*kernel_stats.csv", recursive=True): shutil.copy(stats, E + "/r04_kernel_stats.csv")
+only_scan("gpurun_out/ev_aa/stats/**/*kernel_trace.csv", E + "/r04_kernel_trace_scan.csv")
 for p in ("sq_a", "sq_b", "fetch", "write"):
-    only_scan("gpurun_out/ev_aa/%s/**/*counter_collection.csv" % p, E + "/r03_pmc_%s_scan_rows.csv" % p)
+    only_scan("gpurun_out/ev_aa/%s/**/*counter_collection.csv" % p, E + "/r04_pmc_%s_scan_rows.csv" % p)
 PY
 fi
 echo "part $part done"

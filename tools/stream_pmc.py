@@ -16,7 +16,10 @@ with open(os.path.join(out, "run.log"), "w") as f:
 rows = []
 for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
     rows += list(csv.DictReader(open(path, newline="")))
-res = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 tools/stream_probe.py --db-rows 50000000 --passes 60", "rc": rc}
+sys.path.insert(0, ROOT)
+import smafa_amd  # (loads the library for its build id; opens no device)
+res = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 tools/stream_probe.py --db-rows 50000000 --passes 60", "rc": rc,
+       "build_id": smafa_amd.build_id()}
 for kernel in ("scan_lazy_kernel<5, 5, 2, 4, false, false>", "scan_zone_few_kernel<5, 5, 2>"):
     mine = [r for r in rows if kernel in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
     # one-query passes only: the probe also runs the same 200 queries as ONE launch (200 query blocks, 200 x the bytes)
