@@ -208,18 +208,14 @@ __device__ __forceinline__ void emit(const ScanArgs &a, RowStageT<ROWS> &rs, int
         uint32_t *c = a.cnt + (size_t)q * a.cnt_stride;
         atomicAdd(c + dist, 1u);
         // Can this pair lower the bound?  Only when it lies strictly below it — and most counted pairs sit ON the bound (the
-        // distance distribution rises steeply towards it): those are done.  The others add up the counts up to their own
-        // distance, eight independent loads in flight at a time (one dependent load per bin made a counted pair cost tens
-        // of microseconds of L2 latency: the k = 50 counting passes spent most of their time here).
+        // distance distribution rises steeply towards it): those are done (k = 50 without a bound, 10 000 queries: 43.7 ->
+        // 32.4 ms of kernels).  The walk itself stays the plain loop: with eight loads in flight it is faster by itself
+        // (29.9 ms) but changes the register allocation of every kernel that inlines this function — the prefilter-off launch
+        // went from 25.4 to 29.2 ms without ever executing it (this form: 26.4); as a real function call: 27.8 ms
+        // (profiles/r04_kth.txt).
         if (dist < ld_relaxed(a.thr + q)) {
             uint32_t seen = 0;
-            for (uint32_t t0 = 0; t0 <= dist; t0 += 8u) {
-                uint32_t v[8];
-#pragma unroll
-                for (uint32_t j = 0; j < 8u; j++) v[j] = ld_relaxed(c + min(t0 + j, dist));
-#pragma unroll
-                for (uint32_t j = 0; j < 8u; j++) seen += t0 + j <= dist ? v[j] : 0u;
-            }
+            for (uint32_t t = 0; t <= dist; t++) seen += ld_relaxed(c + t);
             if (seen >= a.k_tight) atomicMin(a.thr + q, dist);
         }
     }

@@ -13,6 +13,9 @@ light="--skip-stats --passes sq_a,fetch,write"
 collect() {  # tag, collect_pmc flags..., -- bench flags
   local tag=$1; shift
   python3 tools/collect_pmc.py --tag $tag "$@" > $E/collect_$tag.log 2>&1 || { echo "collect $tag failed"; tail -5 $E/collect_$tag.log; return 1; }
+  # the raw rocprofv3 output stays on the box (gpurun merges at most 64 MiB back): the record is what travels; ev_aa's CSVs are
+  # cut down to the scan kernel's rows at the end of part a
+  [ "$tag" = ev_aa ] || rm -rf gpurun_out/$tag/sq_a gpurun_out/$tag/sq_b gpurun_out/$tag/fetch gpurun_out/$tag/write gpurun_out/$tag/stats gpurun_out/$tag/*_full.json
   echo "collected $tag ($(date +%T))"
 }
 if [ "$part" = a ]; then
@@ -94,6 +97,8 @@ for stats in glob.glob("gpurun_out/ev_aa/stats/**/*kernel_stats.csv", recursive=
 only_scan("gpurun_out/ev_aa/stats/**/*kernel_trace.csv", E + "/r04_kernel_trace_scan.csv")
 for p in ("sq_a", "sq_b", "fetch", "write"):
     only_scan("gpurun_out/ev_aa/%s/**/*counter_collection.csv" % p, E + "/r04_pmc_%s_scan_rows.csv" % p)
+for d in ("sq_a", "sq_b", "fetch", "write", "stats"): shutil.rmtree("gpurun_out/ev_aa/" + d, ignore_errors=True)
 PY
 fi
+if [ "$part" = c ]; then rm -rf gpurun_out/ev_cluster/cluster_* gpurun_out/stream_pmc; fi
 echo "part $part done"
