@@ -64,7 +64,7 @@ def per_call(rows, calls):
     """counter totals over EVERY scan kernel dispatch of the run, divided by the number of identical calls the run made
     (mode besthit: one smafa_scan_hits call is a ladder of scans; cluster: calls = 1, the whole run)"""
     # (the k-th modes' bound kernel and row filter belong to the call as well)
-    mine = [r for r in rows if any(k in r["Kernel_Name"] for k in ("smafa::scan_", "kth_from_counts_kernel", "filter_rows_kernel"))]
+    mine = [r for r in rows if any(k in r["Kernel_Name"] for k in ("smafa::scan_", "kth_seed_kernel", "kth_from_counts_kernel", "filter_rows_kernel"))]
     if not mine:
         return {}, 0, 0.0, {}
     disp, by_kernel = {}, {}
