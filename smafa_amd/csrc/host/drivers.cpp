@@ -618,7 +618,12 @@ static int cluster_load(const char *input_fasta, int alphabet, int device, Clust
     std::thread warm(warm_device, device);  // device bring-up overlaps the parse
     BulkRecords &recs = in.recs;
     int rc = load_records_bulk(input_fasta, alphabet, true, recs);  // src/cluster.rs:28,35-43 for every record
-    warm.join();
+    struct Joiner {  // the bring-up is waited for after the duplicates have been found too (they need no device)
+        std::thread &t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } joiner{warm};
     if (rc) return expect_fastx(rc, "valid path/file of input fasta");  // src/cluster.rs:28
     if (recs.n >= 0xfffffff0ull) return set_error(SMAFA_ERR_INVALID, "too many records");
     if (recs.err_kind == 1) {  // src/lib.rs:38-41
@@ -644,6 +649,10 @@ static int cluster_load(const char *input_fasta, int alphabet, int device, Clust
         log_line(2, "parsed %llu records in %.2f s, %zu distinct found in %.2f s", (unsigned long long)recs.n,
                  t_loaded - in.t_start, in.uniq.size(), now_seconds() - t_loaded);
     }
+    const double t_wait = now_seconds();
+    warm.join();
+    log_line(2, "device bring-up: waited %.2f s for it after the load (%.2f s since the start)", now_seconds() - t_wait,
+             now_seconds() - in.t_start);
     return SMAFA_OK;
 }
 
@@ -928,6 +937,7 @@ static int cluster_run(const ClusterInput &in, uint32_t max_divergence, int out_
             log_line(2, "%zu lines written in %.2f s (%.2f s of formatting + writing overlapped with the scans, %.2f s after the last batch)",
                      lines_written, t_write_busy, t_write_busy - std::min(t_write_busy, now_seconds() - t_out), now_seconds() - t_out);
         }
+        log_line(2, "cluster: %.3f s from the start of the load to the last line", now_seconds() - t_start);
         log_line(1, "Clustering complete, took %llu seconds. Clustered %llu sequences into %zu clusters.",  // src/cluster.rs:87-92
                  (unsigned long long)(now_seconds() - t_start), (unsigned long long)n, centroid_rec.size());
     }

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <time.h>
 #include <unistd.h>
 
 #include <string>
@@ -50,7 +51,14 @@ static bool parse_u32(const char *s, uint32_t *out) {
     return true;
 }
 
+static double wall_now() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int main(int argc, char **argv) {
+    const double t_main = wall_now();
     // top-level -v/--verbose and -q/--quiet in front of the subcommand (src/main.rs:67-68); the reference takes its log level
     // from the subcommand's own flags (set_log_level(m, true), :17,34,40,47), so these are accepted and change nothing
     int first = 1;
@@ -166,6 +174,7 @@ int main(int argc, char **argv) {
     } else {
         return usage(("unrecognized subcommand " + cmd).c_str());
     }
+    if (verbosity >= 2) fprintf(stderr, "[DEBUG smafa] %s: %.3f s inside main()\n", cmd.c_str(), wall_now() - t_main);
     int code = 0;
     if (rc != SMAFA_OK) {
         fprintf(stderr, "%s\n", smafa_last_error());

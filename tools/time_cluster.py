@@ -10,7 +10,7 @@ for rep in range(3):  # wall of the whole CLI run, stdout to a file (the first r
     t = time.time()
     r = subprocess.run([_lib.CLI_PATH, "cluster", "-i", "/tmp/cluster.faa", "-d", "5", "--alphabet", "aa", "-v"], stdout=open("/tmp/cluster.out", "wb"), stderr=subprocess.PIPE)
     dt = time.time() - t
-    print("run %d: %.3f s  | %s" % (rep, dt, " | ".join(l.split("smafa] ")[1] for l in r.stderr.decode(errors="replace").splitlines() if any(k in l for k in ("parsed", "batches", "scan kernels", "lines written")))), flush=True)
+    print("run %d: %.3f s  | %s" % (rep, dt, " | ".join(l.split("smafa] ")[1] for l in r.stderr.decode(errors="replace").splitlines() if any(k in l for k in ("parsed", "bring-up", "batches", "scan kernels", "lines written", "from the start", "inside main")))), flush=True)
 lines = sum(1 for _ in open("/tmp/cluster.out", "rb"))
 cents = len(set(l.split(b"\t")[1] for l in open("/tmp/cluster.out", "rb")))
 print("cluster rc=%d %.3fs records=%d lines=%d centroids=%d stderr=%s" % (r.returncode, dt, len(recs), lines, cents, r.stderr[-300:]))
