@@ -1180,10 +1180,12 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
     const bool laddered = k_mode >= 1 && db->use_filter && db->lazy && db->two_phase && n_queries >= 16;
     // Which LATER steps pay is estimated once, on a sample of the queries the first step left open: every (cur_n / 256)-th
     // open query is scanned in the k-th mode at the ladder's last bound, and the distribution of their k-th distances says
-    // what share of the open queries each later step would finish.  A step costs about 0.3 (bounds the OR-fold still
-    // rejects at), 0.4 (FOLD 1: the filter plane's per-word sums) or 0.5 (FOLD 2: two planes) of what the loose path costs
-    // per query (10M x 60 aa, 10 000 queries: 8.4 / 12 / 15 / 29 ms, profiles/r03_bench.json); the cheapest sequence of
-    // steps + loose path for the rest wins.
+    // what share of the open queries each later step would finish.  A step costs about 0.37 (bounds the OR-fold still
+    // rejects at), 0.5 (FOLD 1: the filter plane's per-word sums) or 0.53 (FOLD 2: two planes) of what the loose path costs
+    // per query (10M x 60 aa, 10 000 queries, best-hit launches: 9.1 / 12.5 / 13.2 ms against 25 ms for queries nothing is near to,
+    // profiles/r04_bound_probe.txt; round 3's 0.3 / 0.4 / 0.5 were taken against a 29 ms loose path: with half the queries
+    // unrelated the step at 12 then cost 7.4 ms to finish what the loose path does in 5.5, profiles/r04_kth.txt); the cheapest
+    // sequence of steps + loose path for the rest wins.
     // (Round 2 stopped after any step that finished less than an eighth: queries 9-14 columns away from their nearest
     // subject — novel members of a family — then paid the loose path in full: 33 ms per 10 000 instead of ~17.)
     std::vector<char> run_step(ladder.size(), 1);
@@ -1230,7 +1232,7 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
                 const uint32_t b = ladder[from + t];
                 size_t fin = 0;
                 for (uint32_t v : kth) fin += v <= b;
-                cost += open_share * (b <= 3u * cols / 8u ? 0.3 : b <= 17u ? 0.4 : 0.5);
+                cost += open_share * (b <= 3u * cols / 8u ? 0.37 : b <= 17u ? 0.5 : 0.53);
                 open_share = 1.0 - (double)fin / (double)ns;
             }
             cost += open_share;

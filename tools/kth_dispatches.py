@@ -6,11 +6,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 k = sys.argv[1] if len(sys.argv) > 1 else "5"
 env = dict(os.environ, TMPDIR="/tmp")
 far = "far" in sys.argv[2:]
-if len(sys.argv) > 2 and sys.argv[2] != "far":
+mixed = "mixed" in sys.argv[2:]
+if len(sys.argv) > 2 and sys.argv[2] not in ("far", "mixed"):
     env["SMAFA_KTH_SAMPLE"] = sys.argv[2]
-out = os.path.join(ROOT, "gpurun_out", "kth_trace_%s_%s%s" % (k, env.get("SMAFA_KTH_SAMPLE", "d"), "_far" if far else ""))
+out = os.path.join(ROOT, "gpurun_out", "kth_trace_%s_%s%s" % (k, env.get("SMAFA_KTH_SAMPLE", "d"), "_far" if far else "_mixed" if mixed else ""))
 subprocess.run(["/opt/rocm/bin/rocprofv3", "--kernel-trace", "-d", out, "-o", "t", "--output-format", "csv", "--",
-                "python3", os.path.join(ROOT, "tools", "kth_one.py"), k] + (["far"] if far else []), cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                "python3", os.path.join(ROOT, "tools", "kth_one.py"), k] + (["far"] if far else ["mixed"] if mixed else []), cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 rows = []
 for p in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
     rows += list(csv.DictReader(open(p, newline="")))
