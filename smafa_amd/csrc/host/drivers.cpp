@@ -782,6 +782,10 @@ static int cluster_run(const ClusterInput &in, uint32_t max_divergence, int out_
         std::vector<uint32_t> cand_pos;        // candidate ordinal -> position in the batch
         std::vector<uint32_t> cand_centroid;   // candidate ordinal -> centroid ordinal it became (or NONE)
         size_t pos = 0, B = 1024, n_batches = 0;
+        // largest batch: a batch costs two scans + an append whatever its size (~2 ms of host round trips), the scans themselves
+        // grow with it; SMAFA_CLUSTER_BATCH overrides (every rank reads the same environment)
+        size_t batch_cap = 65536;
+        if (const char *bc = getenv("SMAFA_CLUSTER_BATCH")) batch_cap = std::max<size_t>(256, strtoull(bc, nullptr, 10));
         double t_old = 0, t_cand = 0, t_seq = 0, t_append = 0;
         while (pos < uniq.size()) {
             n_batches++;
@@ -908,7 +912,7 @@ static int cluster_run(const ClusterInput &in, uint32_t max_divergence, int out_
             // batch size follows the row volume: grow while the scans stay cheap, shrink on dense input
             // (from exchanged quantities only, so every rank takes the same decision)
             const size_t volume = (nb - cand_pos.size()) + cand_hits.size();
-            if (volume < (4u << 20) && B < 65536) B *= 2;
+            if (volume < (4u << 20) && B < batch_cap) B *= 2;
             else if (volume > (16u << 20) && B > 256) B /= 2;
         }
 
