@@ -142,6 +142,7 @@ struct smafa_db {
     bool fold3 = true;        // scan_kernel's all-planes-but-the-last bound for launches whose bound starts above 32 (SMAFA_FOLD3=0)
     bool stream_nt = true;    // one-query-block launches of scan_lazy_kernel load their filter words non-temporally (SMAFA_STREAM_NT=0)
     uint32_t count_first_k = 3;  // smallest k whose loose-bound scans count first and append second (SMAFA_COUNT_FIRST_K)
+    bool ladder_probe = true;    // the ladder's first step is asked of a 256-query sample before the whole batch pays for it (SMAFA_LADDER_PROBE=0)
     bool zone_direct = true;     // fixed-bound zone launches without LDS staging and barriers (SMAFA_ZONE_DIRECT=0: the staged form)
     bool lazy_fold = true;       // the filter-plane-resident kernel also at the bounds only its level 2 rejects at (SMAFA_LAZY_FOLD=0)
     bool kth_hist_seed = true;   // k >= 2: the seed bound from an LDS histogram over the first tiles (SMAFA_KTH_HIST_SEED=0: a counting launch)
@@ -1249,6 +1250,43 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
                  ns, chosen.c_str(), best_cost);
         return SMAFA_OK;
     };
+    // Does the FIRST step finish anybody?  On queries unrelated to the store (or a k that wants more neighbours than a family has)
+    // it costs a full zone-kernel pass and finishes nobody (2.2 ms per 10 000 queries at 10M subjects: 14 % of a batch of unrelated
+    // queries, 7 % of a k = 5 call).  Asked of every (n / 256)-th query first (0.1-0.2 ms): below a sixteenth of the sample finished,
+    // the step is skipped and the later steps are planned right away.  Exact either way (a skipped step only moves queries to a
+    // later, looser scan).
+    if (laddered && db->ladder_probe && n_queries >= 2048 && !ladder.empty() && limit > ladder[0]) {
+        const uint32_t ns = 256, stride = (uint32_t)(n_queries / ns);
+        std::vector<uint8_t> sample((size_t)ns * db->L);
+        for (uint32_t i = 0; i < ns; i++) memcpy(&sample[(size_t)i * db->L], query_codes + (size_t)i * stride * db->L, db->L);
+        rc = qset_fill(&db->scratch_q3, db, sample.data(), ns);
+        if (rc) return rc;
+        unsigned long long count = 0;
+        // (a plain fixed-bound launch — every pair within the bound — not the step's tightening form with its seed and growing
+        // segments: seven small launches cost the sample more than the answer is worth)
+        rc = scan_range(db, &db->scratch_q3, 0, ns, ladder[0], 0, db->hits.as<smafa_hit>(), db->hits_cap(),
+                        db->count.as<unsigned long long>());
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(&count, db->count.p, sizeof count, hipMemcpyDeviceToHost, db->stream));
+        HIP_TRY(hipStreamSynchronize(db->stream));
+        note_call_scan(db);
+        uint32_t finished = ns;  // (too dense to look at: the step will finish plenty)
+        if (count <= db->hits_cap()) {
+            std::vector<smafa_hit> rows;
+            rc = fetch_rows(db, count, 0, ns, rows);
+            if (rc) return rc;
+            std::vector<uint32_t> have(ns, 0);
+            for (const smafa_hit &h : rows) have[h.query]++;
+            finished = 0;
+            for (uint32_t v : have) finished += v >= k_mode;
+        }
+        if (finished * 16u < ns) {
+            run_step[0] = 0;
+            log_line(2, "near-hit probe: %u of %u sampled queries finish at bound %u: the step is skipped", finished, ns, ladder[0]);
+            rc = plan_later_steps(1);
+            if (rc) return rc;
+        }
+    }
     for (size_t step = 0; laddered && step < ladder.size() && cur_n >= 16; step++) {
         const uint32_t bound = ladder[step];
         if (limit <= bound || (step > 0 && bound <= ladder[step - 1])) break;
@@ -1445,6 +1483,7 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     if (const char *f3 = getenv("SMAFA_FOLD3")) db->fold3 = atoi(f3) != 0;
     if (const char *sn = getenv("SMAFA_STREAM_NT")) db->stream_nt = atoi(sn) != 0;
     if (const char *cv = getenv("SMAFA_COUNT_FIRST_K")) db->count_first_k = (uint32_t)std::max(2, atoi(cv));
+    if (const char *lp = getenv("SMAFA_LADDER_PROBE")) db->ladder_probe = atoi(lp) != 0;
     if (const char *zd = getenv("SMAFA_ZONE_DIRECT")) db->zone_direct = atoi(zd) != 0;
     if (const char *lf = getenv("SMAFA_LAZY_FOLD")) db->lazy_fold = atoi(lf) != 0;
     if (const char *ks = getenv("SMAFA_KTH_HIST_SEED")) db->kth_hist_seed = atoi(ks) != 0;

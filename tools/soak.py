@@ -28,7 +28,7 @@ SWITCHES = {"SMAFA_FILTER": ["1", "1", "1", "0"], "SMAFA_LAZY": ["1", "1", "0"],
             "SMAFA_ZONE": ["1", "1", "2", "2", "0"], "SMAFA_SORT": ["1", "1", "0"], "SMAFA_LAYOUT": ["1", "1", "0"],
             "SMAFA_RESORT": ["1", "1", "1", "0"], "SMAFA_RESORT_MIN": ["", "2", "300", "5000"], "SMAFA_FOLD3": ["1", "1", "0"], "SMAFA_STREAM_NT": ["1", "1", "0"],
             # round 4: the k-th modes' counting pass over a sample of the tiles (forced onto small stores), or over everything
-            "SMAFA_ZONE_DIRECT": ["1", "1", "0"], "SMAFA_LAZY_FOLD": ["1", "1", "0"], "SMAFA_KTH_SAMPLE": ["16", "2", "4", "0"], "SMAFA_KTH_HIST_SEED": ["1", "1", "0"], "SMAFA_KTH_SAMPLE_MIN_TILES": ["2", "8", "4096"]}
+            "SMAFA_ZONE_DIRECT": ["1", "1", "0"], "SMAFA_LADDER_PROBE": ["1", "1", "0"], "SMAFA_LAZY_FOLD": ["1", "1", "0"], "SMAFA_KTH_SAMPLE": ["16", "2", "4", "0"], "SMAFA_KTH_HIST_SEED": ["1", "1", "0"], "SMAFA_KTH_SAMPLE_MIN_TILES": ["2", "8", "4096"]}
 print("soak seed", seed0, flush=True)
 t_note = time.time()
 while time.time() < t_end:
