@@ -1977,14 +1977,36 @@ __global__ __launch_bounds__(256) void kth_seed_kernel(const uint4 *__restrict__
     // took 6.4 ms that way, 4x the comparison itself).  The counts stay complete up to the bound, which never drops below
     // this workgroup's own k-th distance, itself an upper bound of the sample's and of the store's.
     __shared__ uint32_t bound_lds[kSeedQueries];
+    // compile-time shapes: the chunk's query records are staged in LDS once (a record read is then a broadcast ds_read, not a
+    // scalar load from global memory whose latency the four waves of a workgroup could not hide: 2.2 -> 1.x ms for the 1/32 sample)
+    constexpr bool kStaged = PS_ && W_;
+    constexpr int kRecWords = kStaged ? qrec_stride(PQ_ ? PQ_ : 1, W_ ? W_ : 1) : 4;
+    __shared__ uint32_t qstage[kSeedQueries * kRecWords];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t i = tid; i < (uint32_t)(kSeedQueries * kSeedBins); i += 256u) (&hist[0][0])[i] = 0u;
-    if (tid < (uint32_t)kSeedQueries) bound_lds[tid] = thr0;
-    __syncthreads();
     const uint32_t chunk = blockIdx.x % n_chunks, group = blockIdx.x / n_chunks;
     const uint32_t q0 = q_begin + chunk * kSeedQueries;
     const uint32_t nq = min((uint32_t)kSeedQueries, q_end - q0);
+    for (uint32_t i = tid; i < (uint32_t)(kSeedQueries * kSeedBins); i += 256u) (&hist[0][0])[i] = 0u;
+    if (tid < (uint32_t)kSeedQueries) bound_lds[tid] = thr0;
+    if (kStaged)
+        for (uint32_t i = tid; i < nq * (uint32_t)kRecWords; i += 256u) qstage[i] = qrec[(size_t)q0 * QS + i];
+    __syncthreads();
     // tile groups are strided sets of 4-tile steps: step s of group g covers tiles 4 * (g + s * n_groups) .. + 3
+    auto update_bounds = [&]() {  // every thread of the workgroup: first d whose cumulative count reaches k, per query
+        __syncthreads();
+        if (tid < nq) {
+            uint32_t seen = 0;
+            const uint32_t old = bound_lds[tid];
+            for (uint32_t d = 0; d <= old && d < (uint32_t)kSeedBins; d++) {
+                seen += hist[tid][d];
+                if (seen >= k) {
+                    bound_lds[tid] = d;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    };
     for (uint32_t step = group; step * kWgWaves < n_tiles; step += n_groups) {  // (uniform trip count per workgroup)
         const uint32_t tile = min(step * kWgWaves + wave, n_tiles - 1u);
         const bool live = step * kWgWaves + wave < n_tiles;  // a wave past the range still meets the others at the barriers
@@ -1996,7 +2018,9 @@ __global__ __launch_bounds__(256) void kth_seed_kernel(const uint4 *__restrict__
         }
         const uint32_t pos = tile * kWaveTile + lane * 4u;
         for (uint32_t qi = 0; qi < nq; qi++) {
-            const uint32_t *rec = qrec + (size_t)(q0 + qi) * QS;
+            const uint32_t *rec_g = qrec + (size_t)(q0 + qi) * QS;
+            const uint32_t *rec_l = &qstage[kStaged ? qi * (uint32_t)kRecWords : 0u];
+#define rec (kStaged ? rec_l : rec_g)
             uint4 d = make_uint4(0, 0, 0, 0);
             for (uint32_t w = 0; w < W; w++) {  // (compile-time trip counts unroll by themselves; the run-time form cannot)
                 uint32_t extra = 0;  // query bits in planes no subject has: a mismatch against every subject
@@ -2015,26 +2039,19 @@ __global__ __launch_bounds__(256) void kth_seed_kernel(const uint4 *__restrict__
                 d.z += __builtin_popcount(m.z);
                 d.w += __builtin_popcount(m.w);
             }
+#undef rec
             const uint32_t bnd = live ? bound_lds[qi] : 0u;
             if (pos + 0 < n_subjects && d.x <= bnd && live) atomicAdd(&hist[qi][d.x], 1u);
             if (pos + 1 < n_subjects && d.y <= bnd && live) atomicAdd(&hist[qi][d.y], 1u);
             if (pos + 2 < n_subjects && d.z <= bnd && live) atomicAdd(&hist[qi][d.z], 1u);
             if (pos + 3 < n_subjects && d.w <= bnd && live) atomicAdd(&hist[qi][d.w], 1u);
         }
-        __syncthreads();
-        if (tid < nq) {  // the bound after this step: first d whose cumulative count reaches k
-            uint32_t seen = 0;
-            const uint32_t old = bound_lds[tid];
-            for (uint32_t d = 0; d <= old && d < (uint32_t)kSeedBins; d++) {
-                seen += hist[tid][d];
-                if (seen >= k) {
-                    bound_lds[tid] = d;
-                    break;
-                }
-            }
-        }
-        __syncthreads();
+        // the bound is brought up to date every 4th step only (a stale, looser bound merely counts a few pairs more): the walk
+        // over a histogram is a chain of ~L dependent LDS reads by 32 threads while the other 224 wait at the barrier — as
+        // long as a whole step's comparisons
+        if ((step / n_groups) % 4u == 3u) update_bounds();
     }
+    update_bounds();  // (also the barrier between the last step's ds_adds and the reads below)
     if (cnt) {  // this group's share of the counts: complete up to its own final bound (bins above it hold what was counted
                 // while the bound was still looser — partial, and never needed: the sample's k-th distance is at most this bound)
         const uint32_t bins = min(min(thr0 + 1u, cnt_stride), (uint32_t)kSeedBins);
