@@ -323,7 +323,11 @@ def compact_line(full: dict, full_path=None) -> dict:
     g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
     cfg = dict(full.get("config") or {})
     cfg["workload"] = str(cfg.get("workload", ""))[:200]
-    cfg.pop("far_frac", None) if cfg.get("mode") != "besthit" else None
+    if cfg.get("mode") != "besthit":
+        cfg.pop("far_frac", None)
+    if cfg.get("mode") != "kth":
+        cfg.pop("kth_k", None)
+        cfg.pop("kth_bounded", None)
     cfg["parallelism"] = str(cfg.get("parallelism", ""))[:80]
     r = full.get("roofline") or {}
     roof = {"bound": r.get("bound"), "kernel": r.get("kernel"), "achieved": sig(r.get("achieved")), "peak": sig(r.get("peak"), 6),
