@@ -722,7 +722,9 @@ static int launch_tiles(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t
     // scan_wide_kernel would otherwise run (one-word stores)
     const bool zone = specialised && !seed && use_zone(db, thr0, prefilter_prunes(db, thr0));
     lazy = lazy || zone;  // (the plan reported by smafa_last_scan_plan: a filter-plane-resident kernel)
-    const uint32_t T = zone ? (q_end - q_begin <= 64u ? (uint32_t)kFewTiles : (uint32_t)kZoneTiles)
+    // (the unstaged form of the zone kernel — launch_zone_t's `direct` — has its own tile count per shape)
+    const bool zone_is_direct = !(k_tight || per_query_bounds) && db->zone_direct && d_rows != nullptr;
+    const uint32_t T = zone ? (q_end - q_begin <= 64u ? (uint32_t)kFewTiles : (uint32_t)zone_tiles((int)db->P, (int)db->W, zone_is_direct))
                      : wide ? (uint32_t)kWideTiles : specialised ? tiles_per_wave(db, lazy, thr0) : (uint32_t)kGenericTiles;
     a.tile_begin = tile_begin;
     a.tile_end = tile_end;

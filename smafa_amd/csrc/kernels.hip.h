@@ -942,6 +942,13 @@ __device__ __forceinline__ void emit_direct(const ScanArgs &a, uint32_t q, uint3
 #define SMAFA_ZONE_TILES 4
 #endif
 constexpr int kZoneTiles = SMAFA_ZONE_TILES;
+// ... per shape: the five-plane two-word kernel (60-column amino acids) takes 6 — without LDS staging and barriers (DIRECT) the
+// per-chunk work is what is left to amortise: 10M x 10k 1.815 -> 1.775 ms, 50M x 125k 53.5 -> 52.1 ms; nucleotides lose a resident
+// wave to the extra filter words: 2.70 -> 3.12 ms (profiles/r04_zone_variants.txt).  SMAFA_ZONE_TILES != 4 overrides for every shape.
+// (the staged instantiations keep 4: with 6 they spill 64-96 bytes)
+__host__ __device__ constexpr int zone_tiles(int ps, int w, bool direct) {
+    return SMAFA_ZONE_TILES != 4 ? SMAFA_ZONE_TILES : (direct && ps == 5 && w == 2 ? 6 : 4);
+}
 // Waves per workgroup of scan_zone_kernel.  The waves of a workgroup share the staged query chunk and meet at one barrier
 // per chunk; fewer waves per workgroup wait less for each other and stage more often.  Measured (profiles/
 // r02_zone_variants.txt): 4 / 2 / 1 waves: aa 1.988 / 1.958 / 1.998 ms, nt (bound 3) 4.079 / 3.953 / 4.044 ms.
@@ -993,7 +1000,7 @@ template <int PS, int PQ, int W, bool FIXED, bool DIRECT = false>
 __global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan_zone_kernel(const uint4 *__restrict__ planes,
                                                            const uint32_t *__restrict__ qrec, ScanArgs a) {
     static_assert(FIXED || !DIRECT, "per-query bounds keep the staged form");
-    constexpr int T = kZoneTiles;
+    constexpr int T = zone_tiles(PS, W, DIRECT);
     constexpr int RS = qrec_stride(PQ, W);
     constexpr int RV = RS / 4;
     constexpr int WGW = kZoneWgWaves;  // waves per workgroup
