@@ -985,7 +985,10 @@ constexpr int kFewTiles = SMAFA_FEW_TILES;  // wave tiles per wave in scan_zone_
 #ifndef SMAFA_ZONE_NLIVE
 #define SMAFA_ZONE_NLIVE 1  // 1: "tile slot t is inside the range" is ONE scalar (the number of live slots) instead of T lane masks
 #endif
-__host__ __device__ constexpr int zone_min_waves(int ps, int w) { return ps * w <= 4 ? 6 : ps * w <= 10 ? SMAFA_ZONE_WAVES_10 : 4; }
+#ifndef SMAFA_ZONE_WAVES_4
+#define SMAFA_ZONE_WAVES_4 6  // waves per SIMD asked for where a tile holds up to 4 vectors (the 2-bit nucleotide store)
+#endif
+__host__ __device__ constexpr int zone_min_waves(int ps, int w) { return ps * w <= 4 ? SMAFA_ZONE_WAVES_4 : ps * w <= 10 ? SMAFA_ZONE_WAVES_10 : 4; }
 
 // FIXED: one bound for every query (a.thr == NULL, the plain --max-divergence scan).  The chunks are then staged by
 // LDS-DMA (global_load_lds_dwordx4: no register hop — the prefetch registers of the other form were being spilled
