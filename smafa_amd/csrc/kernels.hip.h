@@ -988,7 +988,14 @@ constexpr int kFewTiles = SMAFA_FEW_TILES;  // wave tiles per wave in scan_zone_
 #ifndef SMAFA_ZONE_WAVES_4
 #define SMAFA_ZONE_WAVES_4 6  // waves per SIMD asked for where a tile holds up to 4 vectors (the 2-bit nucleotide store)
 #endif
-__host__ __device__ constexpr int zone_min_waves(int ps, int w) { return ps * w <= 4 ? SMAFA_ZONE_WAVES_4 : ps * w <= 10 ? SMAFA_ZONE_WAVES_10 : 4; }
+#ifndef SMAFA_ZONE_WAVES_6
+#define SMAFA_ZONE_WAVES_6 6  // ... for the three-plane two-word shape (nucleotides with N at 60 columns: 6 vectors per tile): 80 VGPRs +
+                              // 8 bytes of scratch instead of 82 / none, one more resident wave: 3.09 -> 2.98 ms (7: the same;
+                              // profiles/r04_zone_variants.txt)
+#endif
+__host__ __device__ constexpr int zone_min_waves(int ps, int w) {
+    return ps * w <= 4 ? SMAFA_ZONE_WAVES_4 : (ps == 3 && w == 2) ? SMAFA_ZONE_WAVES_6 : ps * w <= 10 ? SMAFA_ZONE_WAVES_10 : 4;
+}
 
 // FIXED: one bound for every query (a.thr == NULL, the plain --max-divergence scan).  The chunks are then staged by
 // LDS-DMA (global_load_lds_dwordx4: no register hop — the prefetch registers of the other form were being spilled
