@@ -942,16 +942,15 @@ __device__ __forceinline__ void emit_direct(const ScanArgs &a, uint32_t q, uint3
 #define SMAFA_ZONE_TILES 4
 #endif
 constexpr int kZoneTiles = SMAFA_ZONE_TILES;
-// ... per shape: the five-plane two-word kernel (60-column amino acids) takes 6 — without LDS staging and barriers (DIRECT) the
-// per-chunk work is what is left to amortise: 10M x 10k 1.815 -> 1.775 ms, 50M x 125k 53.5 -> 52.1 ms; nucleotides lose a resident
-// wave to the extra filter words: 2.70 -> 3.12 ms (profiles/r04_zone_variants.txt).  SMAFA_ZONE_TILES != 4 overrides for every shape.
-// (the staged instantiations keep 4: with 6 they spill 64-96 bytes)
+// ... per shape and form.  The UNSTAGED five-plane two-word kernel (60-column amino acids, fixed bound) takes 2 tiles per wave at
+// 7 waves per SIMD (72 VGPRs): without LDS staging and barriers there is little per-chunk work left to amortise over more tiles,
+// and every resident wave more hides more of the survivor loop's dependent slow-class chain.  Same box, ms per launch, 10M x 10k /
+// 50M x 125k (profiles/r04_zone_variants.txt): 5 waves x 4 tiles 1.795 / 53.5, 5 x 6 1.77 / 52.0, 6 x 3 1.71 / 50.6, 6 x 2 1.72 /
+// 51.5, **7 x 2 1.68 / 49.3**, 7 x 3 1.76 / 64.6 (spills), 8 x 2 1.78 / 78.4 (spills), 4 x 6 1.95, 6 x 4 2.01.  Nucleotides keep 4
+// tiles (3: 2.80, 6: 3.12 vs 2.70 ms).  SMAFA_ZONE_TILES != 4 overrides for every shape.
 __host__ __device__ constexpr int zone_tiles(int ps, int w, bool direct) {
-    return SMAFA_ZONE_TILES != 4 ? SMAFA_ZONE_TILES : (direct && ps == 5 && w == 2 ? 6 : 4);
+    return SMAFA_ZONE_TILES != 4 ? SMAFA_ZONE_TILES : (direct && ps == 5 && w == 2 ? 2 : 4);
 }
-// Waves per workgroup of scan_zone_kernel.  The waves of a workgroup share the staged query chunk and meet at one barrier
-// per chunk; fewer waves per workgroup wait less for each other and stage more often.  Measured (profiles/
-// r02_zone_variants.txt): 4 / 2 / 1 waves: aa 1.988 / 1.958 / 1.998 ms, nt (bound 3) 4.079 / 3.953 / 4.044 ms.
 #ifndef SMAFA_ZONE_WG_WAVES
 #define SMAFA_ZONE_WG_WAVES 2
 #endif
@@ -993,8 +992,12 @@ constexpr int kFewTiles = SMAFA_FEW_TILES;  // wave tiles per wave in scan_zone_
                               // 8 bytes of scratch instead of 82 / none, one more resident wave: 3.09 -> 2.98 ms (7: the same;
                               // profiles/r04_zone_variants.txt)
 #endif
-__host__ __device__ constexpr int zone_min_waves(int ps, int w) {
-    return ps * w <= 4 ? SMAFA_ZONE_WAVES_4 : (ps == 3 && w == 2) ? SMAFA_ZONE_WAVES_6 : ps * w <= 10 ? SMAFA_ZONE_WAVES_10 : 4;
+#ifndef SMAFA_ZONE_WAVES_DIRECT_AA
+#define SMAFA_ZONE_WAVES_DIRECT_AA 7  // the unstaged five-plane two-word kernel (see zone_tiles)
+#endif
+__host__ __device__ constexpr int zone_min_waves(int ps, int w, bool direct = false) {
+    return (direct && ps == 5 && w == 2 && SMAFA_ZONE_TILES == 4) ? SMAFA_ZONE_WAVES_DIRECT_AA
+           : ps * w <= 4 ? SMAFA_ZONE_WAVES_4 : (ps == 3 && w == 2) ? SMAFA_ZONE_WAVES_6 : ps * w <= 10 ? SMAFA_ZONE_WAVES_10 : 4;
 }
 
 // FIXED: one bound for every query (a.thr == NULL, the plain --max-divergence scan).  The chunks are then staged by
@@ -1007,7 +1010,7 @@ __host__ __device__ constexpr int zone_min_waves(int ps, int w) {
 // guards every LDS read of a staged record with s_waitcnt vmcnt(0) — it cannot tell the buffer being read from the one the
 // next chunk's LDS-DMA is landing in — so each wave stalled on its own prefetch once per chunk.
 template <int PS, int PQ, int W, bool FIXED, bool DIRECT = false>
-__global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W)) void scan_zone_kernel(const uint4 *__restrict__ planes,
+__global__ __launch_bounds__(kZoneWgWaves * 64, zone_min_waves(PS, W, DIRECT)) void scan_zone_kernel(const uint4 *__restrict__ planes,
                                                            const uint32_t *__restrict__ qrec, ScanArgs a) {
     static_assert(FIXED || !DIRECT, "per-query bounds keep the staged form");
     constexpr int T = zone_tiles(PS, W, DIRECT);
