@@ -98,6 +98,7 @@ def parse_args(argv=None):
                     help="testing only: the BASELINE configs block with every size multiplied by this (and run whatever the timed "
                          "workload is), so that the line's length can be checked with every leg present")
     ap.add_argument("--no-kth", action="store_true", help="skip the k-th-mode leg (--max-num-hits 5 / 50)")
+    ap.add_argument("--no-index", action="store_true", help="skip the block-index legs (smafa_db_build_index)")
     return ap.parse_args(argv)
 
 
@@ -380,6 +381,12 @@ def compact_line(full: dict, full_path=None) -> dict:
         if isinstance(leg, dict):
             legs[name] = [sig(leg.get("wall_ms")), sig(leg.get("queries_per_s_wall")), sig(g(leg, "roofline", "frac")),
                           leg.get("verified"), sig(leg.get("kernel_ms"))]
+    def idx(leg):  # [kernel ms, query seqs/s, x the scan kernels, verified, build ms]
+        return [sig(leg.get("kernel_ms")), sig(leg.get("queries_per_s")), sig(leg.get("times_the_scan_kernels"), 3), leg.get("verified"),
+                sig(g(leg, "index", "build_ms_call"), 3)]
+
+    if full.get("indexed"):
+        legs["idx"] = idx(full["indexed"])
     ha = full.get("host_api")
     if ha:
         legs["host_api"] = [sig(ha.get("ms_per_batch")), sig(ha.get("queries_per_s")), None, ha.get("rows_identical_to_device_launch")]
@@ -393,6 +400,8 @@ def compact_line(full: dict, full_path=None) -> dict:
                          sig(g(leg, "stages", "scan_kernels_ms")), sig(g(leg, "cpu_baseline", "extrapolated_full_run_s"))]
         else:
             legs[key] = [sig(leg.get("kernel_ms")), sig(leg.get("queries_per_s")), sig(g(leg, "roofline", "frac")), leg.get("verified")]
+            if leg.get("indexed"):
+                legs[key + "i"] = idx(leg["indexed"])
     out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                     "scaling", "vs_baseline", "dtype", "data")}
     out["value"], out["ms_per_step"] = sig(out["value"], 7), sig(out["ms_per_step"], 6)
@@ -401,7 +410,8 @@ def compact_line(full: dict, full_path=None) -> dict:
                 "legs": legs,
                 "legs_key": "[ms (kernel; wall for besthit*/kth*/host_api; cfg4: wall s), query seqs/s (cfg4: records/s), "
                             "roofline frac, verified, ..]; unfiltered/boundN: [kernel ms, frac, verified]; kth*: 5th = kernel ms; "
-                            "cfg4: 5th = scan kernel ms, 6th = CPU s extrapolated by pairs from a prefix",
+                            "cfg4: 5th = scan kernel ms, 6th = CPU s extrapolated by pairs from a prefix; idx/cfgNi (opt-in block index on the same "
+                            "store): [kernel ms, query seqs/s, x the scan kernels, verified, build ms]",
                 "gathered_bytes_per_rank_per_step": full.get("gathered_bytes_per_rank_per_step"),
                 "run_s": full.get("run_s"), "skipped_for_time": [s_.get("leg") for s_ in full.get("skipped_for_time") or []],
                 "full_record": full_path})
@@ -471,6 +481,32 @@ class Bench:
         e1.record(self.stream)
         self.torch.cuda.synchronize()
         return float(self.np.median(ms)), e0.elapsed_time(e1) / reps
+
+
+    def indexed_leg(self, store, qset, D, Q, scan_kernel_ms, reps=20):
+        """the same fixed-bound launch answered from the store's block index (smafa_db_build_index: D + 1 probes per query
+        instead of a pass over every subject) — an opt-in for callers that scan one resident store many times.  Rows must
+        be those of the scan kernels' launch, byte for byte once both lists are ordered."""
+        n0, rows0 = self.launch_rows(store, qset, D)
+        t = time.perf_counter()
+        info = store.build_index(D)
+        build_call_ms = (time.perf_counter() - t) * 1e3
+        n1, rows1 = self.launch_rows(store, qset, D)
+        name = store.last_scan_kernel()
+        out = {"max_divergence": D, "served": "index_probe" in name, "kernel": name,
+               "index": {"blocks": info["blocks"], "bytes": info["bytes"], "build_ms_device": info["build_ms"],
+                         "build_ms_call": build_call_ms, "longest_run": info["longest_run"],
+                         "candidates_per_query": info["candidates_per_query"], "max_div_served": info["max_div_served"]},
+               "rows": n1, "verified": bool(n0 == n1 and rows0.tobytes() == rows1.tobytes()),
+               "checks": "ordered rows byte-identical to the scan kernels' launch on the same resident store and query set"}
+        if out["served"]:
+            k_ms, w_ms = self.kernel_ms(store, qset, D, reps)
+            out.update({"kernel_ms": k_ms, "wall_ms_per_launch": w_ms, "queries_per_s": Q / (k_ms * 1e-3),
+                        "queries_per_s_wall": Q / (w_ms * 1e-3), "scan_kernel_ms": scan_kernel_ms,
+                        "times_the_scan_kernels": scan_kernel_ms / k_ms if k_ms else None,
+                        "launches_to_repay_the_build": build_call_ms / max(scan_kernel_ms - k_ms, 1e-9)})
+        store.drop_index()
+        return out
 
 
 def verify_rows(np, subj, qry, rows, D, planted_row=None, planted_subs=None):
@@ -905,6 +941,12 @@ def main() -> int:
                                                         "scan kernels of one call", k_med, Q * N, alg_bytes_main, build_id)}
                 ok = ok and bool(v)
 
+    # ---- the block index (opt-in, smafa_db_build_index): the metric's launch answered by D + 1 probes per query
+    indexed = None
+    if side_legs and args.mode == "scan" and args.prefilter and not args.no_index and in_budget("indexed", 6):
+        indexed = B.indexed_leg(store, qset, D, Q, kernel_ms_avg)
+        ok = ok and indexed["verified"]
+
     # ---- stream mode: ONE query per pass — the HBM-bound form (north_star's literal "broadcast each query against
     #      all subjects"); three fractions of the 8 TB/s peak + the box's empirical read ceiling.
     def stream_leg(the_store, the_info, queries, n_rows_store, label, reps=200):
@@ -1190,6 +1232,10 @@ def main() -> int:
                 "roofline": roofline_block(c_cfg, kname, k_ms, q * n, q * n * L * bits // 8, build_id),
                 "setup_s": {"generate": tg, "pack_upload": tp},
             }
+            if not args.no_index and in_budget("indexed " + name, 4 + n // 5_000_000):
+                configs[name]["indexed"] = B.indexed_leg(st_c, qs_c, d, q, k_ms, 5 if n >= 50_000_000 else 10)
+                v = v and configs[name]["indexed"]["verified"]
+                configs[name]["verified"] = bool(v)
             if n <= (256 << 20) // int(i_c.bytes_per_subject):
                 configs[name]["cache_note"] = "the packed store (%d MB) fits the 256 MB Infinity Cache" % (i_c.hbm_bytes >> 20)
             extra = None
@@ -1305,6 +1351,7 @@ def main() -> int:
             "loose_bounds": loose,
             "besthit_unbounded": besthit,
             "kth": kth,
+            "indexed": indexed,
             "related": related,
             "host_api": host_api,
             "configs": configs,

@@ -65,6 +65,20 @@ typedef struct {
     uint64_t bytes_per_subject;
 } smafa_db_info_t;
 
+/* state of a store's block index (smafa_db_build_index) */
+typedef struct {
+    int32_t mode;              /* smafa_set_index */
+    int32_t current;           /* 1: an index exists and matches the store as it is now */
+    uint32_t blocks;           /* column blocks the index holds: bounds up to blocks - 1 */
+    uint32_t usable_blocks;    /* ... of which this many have no run of equal keys too long to probe */
+    uint32_t max_div_served;   /* largest bound a big batch is answered from the index at (SMAFA_NONE: none) */
+    uint32_t probe_launches;   /* scans of this handle's life that were answered from an index */
+    uint64_t bytes;            /* HBM the index occupies */
+    uint64_t longest_run;      /* most subjects sharing one block's columns exactly */
+    double candidates_per_query; /* subjects a query drawn like the store's rows is compared with at max_div_served */
+    double build_ms;
+} smafa_index_info_t;
+
 /* ------------------------------------------------------------------ library */
 const char *smafa_last_error(void);
 int smafa_device_count(void); /* 0 when no MI355X is visible; never fails */
@@ -188,6 +202,24 @@ int smafa_set_prefilter(smafa_db *db, int enabled);
  * pass streams the prefilter's plane: the HBM-bound form), 2 = whenever the filter-plane-resident kernel runs.  Results
  * are identical in every mode. */
 int smafa_set_zone_level(smafa_db *db, int mode);
+/* The block index of a resident store — for callers that scan the same store many times with a tight fixed bound (a service,
+ * `smafa cluster`'s batches).  The L columns are cut into max_divergence + 1 disjoint blocks; a subject within d <= max_divergence
+ * of a query agrees with it on every column of at least one of any d + 1 blocks (it has at most d mismatching columns), so a
+ * fixed-bound scan probes d + 1 blocks per query in per-block sorted key arrays and compares in full only the subjects that
+ * share a block with the query: the rows of get_distances (src/lib.rs:71-89) + the bound test of :252/:299 without visiting
+ * the other subjects.  Exact — the rows are those of the scan kernels, in the same unordered list.  smafa_scan_launch /
+ * smafa_scan_hits / the group and session calls use it by themselves when it is current (no append, re-sort or re-plane since
+ * it was built), the bound is within it, the batch has more than 64 queries and the store's blocks are selective enough
+ * (smafa_index_info().max_div_served; dense families and low-complexity columns are left to the scan kernels); otherwise
+ * they scan as before.  Costs 8 bytes x blocks per subject of HBM and about a millisecond per block and 10M subjects to build.
+ * Rows of up to 128 columns. */
+int smafa_db_build_index(smafa_db *db, uint32_t max_divergence);
+int smafa_db_drop_index(smafa_db *db);
+int smafa_index_info(const smafa_db *db, smafa_index_info_t *info);
+/* 0: a built index is never used; 1 (default): used where it pays; 2: also BUILT by the first big fixed-bound scan that could
+ * use one (a synchronous build inside that call); 3: built once the scans that could have used one have cost as much kernel
+ * time as the build would (rent or buy: at most twice the best choice in hindsight).  Results are identical in every mode. */
+int smafa_set_index(smafa_db *db, int mode);
 
 /* ------------------------------------------------- the same store on several GPUs */
 /*

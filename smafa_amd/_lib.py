@@ -27,7 +27,7 @@ EXPORTS = [
     "smafa_db_create", "smafa_db_append", "smafa_db_save", "smafa_db_load", "smafa_db_info", "smafa_db_set_stream", "smafa_db_destroy",
     "smafa_scan_hits", "smafa_distances", "smafa_qset_create", "smafa_qset_destroy", "smafa_scan_launch",
     "smafa_scan_each", "smafa_last_call_stats", "smafa_launch_device",
-    "smafa_sync", "smafa_last_scan_ms", "smafa_last_scan_plan", "smafa_last_scan_kernel", "smafa_build_id", "smafa_hbm_read_probe", "smafa_set_query_block", "smafa_set_prefilter", "smafa_set_zone_level", "smafa_select_rows", "smafa_write_rows",
+    "smafa_sync", "smafa_last_scan_ms", "smafa_last_scan_plan", "smafa_last_scan_kernel", "smafa_build_id", "smafa_hbm_read_probe", "smafa_set_query_block", "smafa_set_prefilter", "smafa_set_zone_level", "smafa_db_build_index", "smafa_db_drop_index", "smafa_index_info", "smafa_set_index", "smafa_select_rows", "smafa_write_rows",
     "smafa_dbfile_write", "smafa_dbfile_read", "smafa_fastx_load", "smafa_fastx_load_partial", "smafa_fastx_load_part", "smafa_free",
     "smafa_group_create", "smafa_group_load", "smafa_group_append", "smafa_group_scan_hits", "smafa_group_size",
     "smafa_group_member", "smafa_group_destroy",
@@ -49,6 +49,14 @@ class DbInfo(C.Structure):
         ("n_subjects", C.c_uint64), ("seq_len", C.c_uint32), ("alphabet", C.c_int32), ("device", C.c_int32),
         ("planes", C.c_uint32), ("words_per_plane", C.c_uint32), ("hbm_bytes", C.c_uint64),
         ("bytes_per_subject", C.c_uint64),
+    ]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32), ("current", C.c_int32), ("blocks", C.c_uint32), ("usable_blocks", C.c_uint32),
+        ("max_div_served", C.c_uint32), ("probe_launches", C.c_uint32), ("bytes", C.c_uint64), ("longest_run", C.c_uint64),
+        ("candidates_per_query", C.c_double), ("build_ms", C.c_double),
     ]
 
 
@@ -109,6 +117,10 @@ def lib() -> C.CDLL:
     l.smafa_set_query_block.argtypes = [vp, C.c_uint32]
     l.smafa_set_prefilter.argtypes = [vp, C.c_int]
     l.smafa_set_zone_level.argtypes = [vp, C.c_int]
+    l.smafa_db_build_index.argtypes = [vp, C.c_uint32]
+    l.smafa_db_drop_index.argtypes = [vp]
+    l.smafa_index_info.argtypes = [vp, C.POINTER(IndexInfo)]
+    l.smafa_set_index.argtypes = [vp, C.c_int]
     l.smafa_group_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_uint32]
     l.smafa_group_load.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int, C.c_char_p]
     l.smafa_group_append.argtypes = [vp, vp, C.c_uint64]

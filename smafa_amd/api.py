@@ -164,6 +164,25 @@ class SubjectStore:
     def set_zone_level(self, mode: int) -> None:
         check(lib().smafa_set_zone_level(self._h, int(mode)))
 
+    def build_index(self, max_divergence: int) -> dict:
+        """the block index of the resident store (smafa_db_build_index): fixed bounds up to max_divergence are then answered
+        by max_divergence + 1 probes per query wherever the store's blocks are selective enough"""
+        check(lib().smafa_db_build_index(self._h, int(max_divergence)))
+        return self.index_info()
+
+    def drop_index(self) -> None:
+        check(lib().smafa_db_drop_index(self._h))
+
+    def set_index(self, mode: int) -> None:
+        check(lib().smafa_set_index(self._h, int(mode)))
+
+    def index_info(self) -> dict:
+        info = _lib.IndexInfo()
+        check(lib().smafa_index_info(self._h, C.byref(info)))
+        d = {k: getattr(info, k) for k, _ in _lib.IndexInfo._fields_}
+        d["max_div_served"] = None if d["max_div_served"] == _lib.NONE else d["max_div_served"]
+        return d
+
     def scan_launch(self, qset: QuerySet, max_divergence: Optional[int], max_num_hits: Optional[int],
                     d_hits: int, cap: int, d_count: int) -> None:
         check(lib().smafa_scan_launch(self._h, qset._h, _opt(max_divergence), _opt(max_num_hits),

@@ -16,6 +16,7 @@
 #include "engine.h"
 #include "host/packed.h"
 #include "kernels.hip.h"
+#include "index.hip.h"
 
 namespace smafa {
 
@@ -155,6 +156,27 @@ struct smafa_db {
     uint64_t retry_key = 0, retry_nq = 0, generation = 0;  // generation: bumped whenever the subjects change
     uint32_t retry_div = 0, retry_k = 0;
     bool retry_valid = false;
+    // ---- block index of the resident store (index.hip.h): built on request (smafa_db_build_index) or on demand (mode 2), tied to
+    // the store's state — any append, re-sort or re-plane leaves it stale and the scan kernels run until it is built again
+    struct BlockIndex {
+        bool valid = false;
+        uint64_t generation = 0, n = 0;
+        uint32_t resorts = 0, P = 0;
+        uint32_t B = 0, dir_bits = 0;
+        uint16_t col_begin[kIndexMaxBlocks + 1] = {0};
+        uint64_t max_run[kIndexMaxBlocks] = {0};  // longest run of equal keys of block b
+        double mean_run[kIndexMaxBlocks] = {0};   // sum(run^2) / n: candidates a query drawn like the store's rows meets there
+        double build_ms = 0.0;
+        DevBuf kp, dir, stats;
+    } index;
+    int index_mode = 1;             // 0: never probed; 1: probed where a built index pays; 2: also built by the first scan that could
+                                    // use one; 3: ... built once such scans have cost what the build would (SMAFA_INDEX)
+    double index_debt_ms = 0.0;     // mode 3: estimated kernel time of the eligible scans since the store last changed
+    uint64_t index_debt_generation = 0;
+    uint64_t index_max_run = 4096;  // a block whose longest run exceeds this is never probed (SMAFA_INDEX_MAX_RUN)
+    double index_cand_per_subject = 4e-6;  // candidates per query the probes may expect, per stored subject (SMAFA_INDEX_CAND)
+    uint64_t index_min_rows = 65536;  // mode 2 builds an index for stores of at least this many subjects (SMAFA_INDEX_MIN_ROWS)
+    uint32_t index_probes = 0;      // launches answered by the index over the handle's life (smafa_index_info)
     size_t tile_words() const { return (size_t)P * W * kWaveTile; }
     uint64_t hits_cap() const { return hits.cap / sizeof(smafa_hit); }
 };
@@ -707,6 +729,161 @@ static uint32_t choose_query_block(const smafa_db *db, uint32_t n_wg_tiles, uint
     return std::max(qb, 1u);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The block index (index.hip.h).
+static bool index_current(const smafa_db *db) {
+    const auto &ix = db->index;
+    return ix.valid && ix.generation == db->generation && ix.n == db->n && ix.resorts == db->resorts && ix.P == db->P;
+}
+
+static void index_drop(smafa_db *db) {
+    db->index.valid = false;
+    for (DevBuf *b : {&db->index.kp, &db->index.dir, &db->index.stats}) b->release();
+}
+
+// Build (or rebuild) the index with `blocks` blocks: serves every fixed bound up to blocks - 1.
+static int index_build(smafa_db *db, uint32_t blocks) {
+    auto &ix = db->index;
+    ix.valid = false;
+    if (db->W > (uint32_t)kIndexMaxWords)
+        return set_error(SMAFA_ERR_INVALID, "the block index takes rows of up to %d columns (this store: %u)", kIndexMaxWords * 32, db->L);
+    if (blocks < 1 || blocks > (uint32_t)kIndexMaxBlocks || blocks > db->L)
+        return set_error(SMAFA_ERR_INVALID, "the block index takes 1..%u blocks for this store (asked: %u)",
+                         std::min<uint32_t>(kIndexMaxBlocks, db->L), blocks);
+    if (db->n == 0 || db->n >= (1ull << 31)) return set_error(SMAFA_ERR_INVALID, "the block index takes 1..2^31-1 subjects");
+    int rc = use_device(db);
+    if (rc) return rc;
+    rc = maybe_resort(db);  // (positions are final afterwards: an index built before a due re-sort would be stale at once)
+    if (rc) return rc;
+    const double t_begin = now_seconds();
+    const uint32_t n = (uint32_t)db->n;
+    uint32_t dir_bits = 8;
+    while (dir_bits < 22 && (1ull << (dir_bits + 2)) < n) dir_bits++;
+    const size_t dir_entries = ((size_t)1 << dir_bits) + 1;
+    rc = ix.kp.ensure((size_t)blocks * n * sizeof(uint2));
+    if (!rc) rc = ix.dir.ensure((size_t)blocks * dir_entries * sizeof(uint32_t));
+    if (!rc) rc = ix.stats.ensure((size_t)kIndexMaxBlocks * 2 * sizeof(unsigned long long));
+    if (!rc) rc = db->keys_a.ensure((size_t)n * sizeof(uint32_t));
+    if (!rc) rc = db->keys_b.ensure((size_t)n * sizeof(uint32_t));
+    if (!rc) rc = db->idx_a.ensure((size_t)n * sizeof(uint32_t));
+    if (!rc) rc = db->idx_b.ensure((size_t)n * sizeof(uint32_t));
+    if (rc) return rc;
+    uint32_t *ka = db->keys_a.as<uint32_t>(), *ia = db->idx_a.as<uint32_t>();
+    uint32_t *kb = db->keys_b.as<uint32_t>(), *ib = db->idx_b.as<uint32_t>();
+    size_t tmp_bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ka, kb, ia, ib, (int)n, 0, 32, db->stream));
+    rc = db->sort_tmp.ensure(tmp_bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ix.stats.p, 0, (size_t)kIndexMaxBlocks * 2 * sizeof(unsigned long long), db->stream));
+    const uint32_t grid = (n + 255u) / 256u;
+    for (uint32_t b = 0; b <= blocks; b++) ix.col_begin[b] = (uint16_t)((uint64_t)b * db->L / blocks);
+    for (uint32_t b = 0; b < blocks; b++) {
+        hipLaunchKernelGGL(index_keys_kernel, dim3(grid), dim3(256), 0, db->stream, db->d_planes, db->P, db->W, n,
+                           (uint32_t)ix.col_begin[b], (uint32_t)ix.col_begin[b + 1], ka, ia);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db->sort_tmp.p, tmp_bytes, ka, kb, ia, ib, (int)n, 0, 32, db->stream));
+        hipLaunchKernelGGL(index_dir_kernel, dim3((uint32_t)((dir_entries + 255) / 256)), dim3(256), 0, db->stream, kb, n, dir_bits,
+                           ix.dir.as<uint32_t>() + (size_t)b * dir_entries);
+        hipLaunchKernelGGL(index_stats_kernel, dim3(std::min<uint32_t>(grid, 2048u)), dim3(256), 0, db->stream, kb, n,
+                           ix.stats.as<unsigned long long>() + (size_t)b * 2);
+        hipLaunchKernelGGL(index_interleave_kernel, dim3(grid), dim3(256), 0, db->stream, kb, ib, n, ix.kp.as<uint2>() + (size_t)b * n);
+        HIP_TRY(hipGetLastError());
+    }
+    unsigned long long st[kIndexMaxBlocks * 2] = {0};
+    HIP_TRY(hipMemcpyAsync(st, ix.stats.p, (size_t)blocks * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, db->stream));
+    HIP_TRY(hipStreamSynchronize(db->stream));
+    for (uint32_t b = 0; b < blocks; b++) {
+        ix.max_run[b] = st[2 * b];
+        ix.mean_run[b] = (double)st[2 * b + 1] / (double)n;
+    }
+    ix.B = blocks;
+    ix.dir_bits = dir_bits;
+    ix.generation = db->generation;
+    ix.n = db->n;
+    ix.resorts = db->resorts;
+    ix.P = db->P;
+    ix.build_ms = (now_seconds() - t_begin) * 1e3;
+    ix.valid = true;
+    if (n > (1u << 20))
+        for (DevBuf *b : {&db->keys_a, &db->keys_b, &db->idx_a, &db->idx_b, &db->sort_tmp}) b->release();
+    log_line(2, "block index of %u rows: %u blocks, %.1f MB, built on the device in %.2f ms", n, blocks,
+             (double)(ix.kp.cap + ix.dir.cap) / 1e6, ix.build_ms);
+    return SMAFA_OK;
+}
+
+// Which blocks a fixed-bound scan would probe, and whether that beats the scan kernels: bound + 1 blocks out of the usable
+// ones (longest run within index_max_run), the ones with the fewest expected candidates; the expected candidates per query
+// must stay within index_cand_per_subject x subjects (a candidate costs ~a dozen scattered 4-byte reads, a scanned subject
+// ~1.7e-14 s of a batched launch: profiles/r04_index.txt).
+static bool index_plan(const smafa_db *db, uint32_t thr0, uint32_t nq, uint8_t *probe_block) {
+    const auto &ix = db->index;
+    if (!db->index_mode || !db->use_filter || !index_current(db) || nq <= 64u || thr0 + 1u > ix.B) return false;
+    uint8_t usable[kIndexMaxBlocks];
+    uint32_t nu = 0;
+    for (uint32_t b = 0; b < ix.B; b++)
+        if (ix.max_run[b] <= db->index_max_run) usable[nu++] = (uint8_t)b;
+    if (nu < thr0 + 1u) return false;
+    std::sort(usable, usable + nu, [&](uint8_t x, uint8_t y) { return ix.mean_run[x] < ix.mean_run[y] || (ix.mean_run[x] == ix.mean_run[y] && x < y); });
+    double expected = 0.0;
+    for (uint32_t j = 0; j <= thr0; j++) expected += ix.mean_run[usable[j]];
+    if (expected > std::max(16.0, db->index_cand_per_subject * (double)db->n)) return false;
+    for (uint32_t j = 0; j <= thr0; j++) probe_block[j] = usable[j];
+    return true;
+}
+
+static int index_probe(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t thr0, const uint8_t *probe_block,
+                       smafa_hit *d_rows, uint64_t rows_cap, unsigned long long *d_count) {
+    const auto &ix = db->index;
+    IndexArgs x;
+    x.kp = ix.kp.as<uint2>();
+    x.dir = ix.dir.as<uint32_t>();
+    x.n = (uint32_t)ix.n;
+    x.dir_bits = ix.dir_bits;
+    x.n_probes = thr0 + 1u;
+    x.bound = thr0;
+    x.L = db->L;
+    x.QS = db->QS;
+    x.q_begin = q_begin;
+    x.q_end = q_end;
+    for (uint32_t j = 0; j < (uint32_t)kIndexMaxBlocks; j++) {
+        x.probe_block[j] = j <= thr0 ? probe_block[j] : 0;
+        x.probe_cols[j] = (uint32_t)ix.col_begin[x.probe_block[j]] | ((uint32_t)ix.col_begin[x.probe_block[j] + 1] << 16);
+    }
+    ScanArgs a{};
+    a.n_subjects = (uint32_t)db->n;
+    a.hits = d_rows;
+    a.cap = rows_cap;
+    a.count = d_count;  // zeroed by the caller; rows are reserved straight from it and it IS the result
+    a.order = db->d_order;
+    const uint64_t groups = (uint64_t)(q_end - q_begin) * x.n_probes;
+    const uint64_t grid = (groups * kIndexGroup + kIndexWg - 1u) / kIndexWg;
+    if (grid > 0x7fffffffull) return set_error(SMAFA_ERR_INVALID, "index probe grid too large (%llu workgroups)", (unsigned long long)grid);
+    int cur_dev = -1;
+    if (hipGetDevice(&cur_dev) == hipSuccess) {
+        db->launch_device = cur_dev;
+        if (cur_dev != db->device) db->launches_off_device++;
+    }
+    const uint32_t *qrec = qs->qrec.as<uint32_t>();
+    bool launched = false;
+#define SMAFA_PROBE(PS_, PQ_, W_)                                                                                             \
+    if (!launched && db->P == PS_ && db->PQ == PQ_ && db->W == W_) {                                                          \
+        hipLaunchKernelGGL((index_probe_kernel<PS_, PQ_, W_>), dim3((uint32_t)grid), dim3(kIndexWg), 0, db->stream, db->d_planes, qrec, x, a); \
+        note_kernel(db, "smafa::index_probe_kernel<%d, %d, %d>", PS_, PQ_, W_);                                               \
+        launched = true;                                                                                                      \
+    }
+    SMAFA_PROBE(2, 3, 1) SMAFA_PROBE(3, 3, 1) SMAFA_PROBE(5, 5, 1) SMAFA_PROBE(2, 3, 2) SMAFA_PROBE(3, 3, 2) SMAFA_PROBE(5, 5, 2)
+    SMAFA_PROBE(2, 3, 3) SMAFA_PROBE(3, 3, 3) SMAFA_PROBE(5, 5, 3) SMAFA_PROBE(2, 3, 4) SMAFA_PROBE(3, 3, 4) SMAFA_PROBE(5, 5, 4)
+#undef SMAFA_PROBE
+    if (!launched) return set_error(SMAFA_ERR_INVALID, "no index probe for %u/%u planes x %u words", db->P, db->PQ, db->W);
+    HIP_TRY(hipGetLastError());
+    db->plan_lazy = 0;
+    db->plan_tiles = 0;
+    db->plan_qblocks = 1;
+    db->last_launches++;
+    db->index_probes++;
+    return SMAFA_OK;
+}
+
 // one kernel launch: queries [q_begin, q_end) x wave tiles [tile_begin, tile_end).  Rows go to `d_rows` (room for
 // `rows_cap`) through the handle's counter; publish != NULL: the launch is the whole scan — its last workgroup writes the
 // row total to *publish and leaves the counters at zero.
@@ -804,6 +981,34 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
     const uint32_t thr0 = std::min<uint32_t>(max_div, db->L);  // a distance never exceeds seq_len
     const uint32_t n_tiles = (uint32_t)((db->n + kWaveTile - 1) / kWaveTile);
     if (k_tight == 0) {
+        // A store with a current block index answers a tight fixed bound from it: bound + 1 probes per query instead of a
+        // pass over every tile (index.hip.h).  Mode 2 builds the index the first time such a scan arrives.
+        if (db->index_mode >= 2 && db->use_filter && nq > 64u && db->W <= (uint32_t)kIndexMaxWords && thr0 + 1u <= std::min<uint32_t>(kIndexMaxBlocks, db->L) &&
+            db->n >= db->index_min_rows && db->n < (1ull << 31) && (!index_current(db) || db->index.B < thr0 + 1u)) {
+            bool build = db->index_mode == 2;
+            if (!build) {
+                // rent or buy: the scans that could have used an index are charged at the batched kernels' measured rate
+                // (1.7e-12 ms per pair and stored vector: profiles/r04_bench_full.json), the build at ~1 ms per block and 10M
+                // subjects (profiles/r04_index.txt); the index is built once the rent paid equals its price
+                if (db->index_debt_generation != db->generation) db->index_debt_ms = 0.0, db->index_debt_generation = db->generation;
+                db->index_debt_ms += (double)nq * (double)db->n * (double)(db->P * db->W) * 1.7e-12;
+                build = db->index_debt_ms >= 0.3 + (double)(thr0 + 1u) * (double)db->n * 1.0e-7;
+            }
+            if (build) {
+                int irc = index_build(db, thr0 + 1u);
+                if (irc) return irc;
+            }
+        }
+        uint8_t probe_block[kIndexMaxBlocks];
+        if (index_plan(db, thr0, nq, probe_block)) {
+            hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, db->stream, (uint32_t *)d_count, 0u, (uint64_t)2);
+            HIP_TRY(hipEventRecord(db->ev0, db->stream));
+            int rc = index_probe(db, qs, q_begin, q_end, thr0, probe_block, d_hits, cap, d_count);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(db->ev1, db->stream));
+            db->timed = true;
+            return SMAFA_OK;
+        }
         // A handful of queries against a big store is a grid of many short-lived workgroups: there the ticket every workgroup
         // takes at its end (to find the last one, which publishes the total) costs more than a tiny fill kernel in front of the launch —
         // the rows are then reserved straight from *d_count (one-query pass over the 50M store: 65 -> 57 us streaming,
@@ -1501,6 +1706,10 @@ int smafa_db_create(smafa_db **out, int device, int alphabet, uint32_t seq_len) 
     if (const char *sv = getenv("SMAFA_PRUNE_P")) db->prune_p = atof(sv);
     if (const char *sv = getenv("SMAFA_RESORT_MIN")) db->resort_min = std::max<uint64_t>(2, strtoull(sv, nullptr, 10));
     if (const char *zl = getenv("SMAFA_ZONE_LOOSE")) db->zone_loose = atof(zl);
+    if (const char *iv = getenv("SMAFA_INDEX")) db->index_mode = std::min(3, std::max(0, atoi(iv)));
+    if (const char *iv = getenv("SMAFA_INDEX_MAX_RUN")) db->index_max_run = std::max<uint64_t>(1, strtoull(iv, nullptr, 10));
+    if (const char *iv = getenv("SMAFA_INDEX_CAND")) db->index_cand_per_subject = atof(iv);
+    if (const char *iv = getenv("SMAFA_INDEX_MIN_ROWS")) db->index_min_rows = std::max<uint64_t>(1, strtoull(iv, nullptr, 10));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) db->n_cu = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&db->own_stream, hipStreamNonBlocking);
@@ -1629,7 +1838,8 @@ void smafa_db_destroy(smafa_db *db) {
     for (DevBuf *b : {&db->upload, &db->hits, &db->count, &db->scratch, &db->ctrs, &db->keys_a, &db->keys_b, &db->sort_tmp,
                       &db->idx_a, &db->idx_b, &db->d_perm, &db->d_tab, &db->scratch_q.qrec,
                       &db->scratch_q.thr, &db->scratch_q.cnt, &db->scratch_q2.qrec, &db->scratch_q2.thr, &db->scratch_q2.cnt,
-                      &db->scratch_q3.qrec, &db->scratch_q3.thr, &db->scratch_q3.cnt})
+                      &db->scratch_q3.qrec, &db->scratch_q3.thr, &db->scratch_q3.cnt, &db->index.kp, &db->index.dir,
+                      &db->index.stats})
         b->release();
     if (db->each_graph) (void)hipGraphExecDestroy(db->each_graph);
     if (db->ev0) (void)hipEventDestroy(db->ev0);
@@ -1724,6 +1934,66 @@ int smafa_set_zone_level(smafa_db *db, int mode) try {
     return SMAFA_OK;
 } catch (...) {
     return smafa::exception_code("smafa_set_zone_level");
+}
+
+int smafa_db_build_index(smafa_db *db, uint32_t max_div) try {
+    if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_db_build_index: NULL handle");
+    if (max_div >= (uint32_t)kIndexMaxBlocks) return set_error(SMAFA_ERR_INVALID, "smafa_db_build_index: bounds up to %d", kIndexMaxBlocks - 1);
+    return index_build(db, max_div + 1u);
+} catch (...) {
+    return smafa::exception_code("smafa_db_build_index");
+}
+
+int smafa_db_drop_index(smafa_db *db) try {
+    if (!db) return set_error(SMAFA_ERR_INVALID, "smafa_db_drop_index: NULL handle");
+    int rc = use_device(db);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(db->stream));
+    index_drop(db);
+    return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_db_drop_index");
+}
+
+int smafa_set_index(smafa_db *db, int mode) try {
+    if (!db || mode < 0 || mode > 3) return set_error(SMAFA_ERR_INVALID, "smafa_set_index: bad argument");
+    db->index_mode = mode;
+    return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_set_index");
+}
+
+int smafa_index_info(const smafa_db *db, smafa_index_info_t *info) try {
+    if (!db || !info) return set_error(SMAFA_ERR_INVALID, "smafa_index_info: NULL argument");
+    memset(info, 0, sizeof *info);
+    const auto &ix = db->index;
+    info->mode = db->index_mode;
+    info->probe_launches = db->index_probes;
+    if (!index_current(db)) return SMAFA_OK;
+    info->current = 1;
+    info->blocks = ix.B;
+    info->bytes = ix.kp.cap + ix.dir.cap;
+    info->build_ms = ix.build_ms;
+    std::vector<double> runs;
+    for (uint32_t b = 0; b < ix.B; b++) {
+        if (ix.max_run[b] > info->longest_run) info->longest_run = ix.max_run[b];
+        if (ix.max_run[b] <= db->index_max_run) runs.push_back(ix.mean_run[b]);
+    }
+    std::sort(runs.begin(), runs.end());
+    info->usable_blocks = (uint32_t)runs.size();
+    // the largest bound the index would answer for a big batch, and the candidates per query expected at it
+    const double limit = std::max(16.0, db->index_cand_per_subject * (double)db->n);
+    double sum = 0.0;
+    info->max_div_served = SMAFA_NONE;
+    for (size_t j = 0; j < runs.size(); j++) {
+        sum += runs[j];
+        if (sum > limit) break;
+        info->max_div_served = (uint32_t)j;
+        info->candidates_per_query = sum;
+    }
+    return SMAFA_OK;
+} catch (...) {
+    return smafa::exception_code("smafa_index_info");
 }
 
 int smafa_set_prefilter(smafa_db *db, int enabled) try {

@@ -24,6 +24,12 @@ def full_record():
     full["cpu_baseline"]["kmode"] = {"value": 1.2345678, "unit": "query seqs/s", "cores": 1, "queries": 4, "max_num_hits": 5,
                                      "sample": "y" * 300}
     full["stream"]["fetched_over_plane"] = 1.0002761030351117
+    ix = {"max_divergence": 5, "served": True, "kernel": "smafa::index_probe_kernel<5, 5, 2>", "kernel_ms": 0.0671234, "verified": True,
+          "queries_per_s": 148981234.5, "times_the_scan_kernels": 25.3456, "index": {"blocks": 6, "build_ms_call": 25.41234}}
+    full["indexed"] = ix
+    for name in full["configs"]:
+        if "cluster" not in name:
+            full["configs"][name]["indexed"] = dict(ix)
     full["skipped_for_time"] = [{"leg": "configs[4] cluster", "at_s": 399.0, "needs_s": 60}]
     return full
 
@@ -53,6 +59,8 @@ def test_compact_line_fits_and_keeps_the_contract():
                  "kth5", "kth50", "kth5_d5", "kth50_d5", "cfg1", "cfg2", "cfg2N", "cfg3", "cfg4"):
         assert name in legs and legs[name][0] > 0, name
     assert legs["cfg2"][3] is True and legs["kth50"][3] is True and legs["cfg4"][5] > 1000
+    for name in ("idx", "cfg1i", "cfg2i", "cfg2Ni", "cfg3i"):
+        assert legs[name] == [0.06712, 149000000.0, 25.3, True, 25.4], (name, legs[name])
     assert out["full_record"] == "gpurun_out/bench_full.json" and out["skipped_for_time"] == ["configs[4] cluster"]
 
 

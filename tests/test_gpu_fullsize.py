@@ -91,6 +91,15 @@ def test_query_scan_full_size(n, q, alphabet, D, max_subs, n_frac):
         assert best[best["query"] == i].tobytes() == grp[grp["dist"] == dmin].tobytes()
     if n == 10_000_000 and q <= 100_000 and n_frac == 0.0:
         kth_modes_full_size(store, subj, qry, alphabet)
+    # the block index (smafa_db_build_index): the same call answered by D + 1 probes per query — the same bytes
+    info = store.build_index(D)
+    assert info["current"] == 1 and info["max_div_served"] == D and info["longest_run"] < 64, info
+    assert store.scan(qry, max_divergence=D).tobytes() == rows.tobytes()
+    assert "index_probe" in store.last_scan_kernel()
+    if D > 1:
+        lower = store.scan(qry, max_divergence=D - 2)
+        assert "index_probe" in store.last_scan_kernel()
+        assert lower.tobytes() == rows[rows["dist"] <= D - 2].tobytes()
     store.close()
 
 
@@ -139,6 +148,9 @@ def test_query_scan_50m_store_one_rank_share():
     check_rows(rows, subj, qry, D)
     assert check_planted(rows, planted_row, planted_subs, D) > 60_000
     sample_vs_oracle(rows, subj, qry, D, rng, k=4)
+    assert store.build_index(D)["max_div_served"] == D  # 6 blocks x 50M (key, position) pairs: 2.4 GB
+    assert store.scan(qry, max_divergence=D).tobytes() == rows.tobytes()
+    assert "index_probe" in store.last_scan_kernel()
     store.close()
 
 

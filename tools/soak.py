@@ -28,7 +28,10 @@ SWITCHES = {"SMAFA_FILTER": ["1", "1", "1", "0"], "SMAFA_LAZY": ["1", "1", "0"],
             "SMAFA_ZONE": ["1", "1", "2", "2", "0"], "SMAFA_SORT": ["1", "1", "0"], "SMAFA_LAYOUT": ["1", "1", "0"],
             "SMAFA_RESORT": ["1", "1", "1", "0"], "SMAFA_RESORT_MIN": ["", "2", "300", "5000"], "SMAFA_FOLD3": ["1", "1", "0"], "SMAFA_STREAM_NT": ["1", "1", "0"],
             # round 4: the k-th modes' counting pass over a sample of the tiles (forced onto small stores), or over everything
-            "SMAFA_ZONE_DIRECT": ["1", "1", "0"], "SMAFA_LADDER_PROBE": ["1", "1", "0"], "SMAFA_LAZY_FOLD": ["1", "1", "0"], "SMAFA_KTH_SAMPLE": ["16", "2", "4", "0"], "SMAFA_KTH_HIST_SEED": ["1", "1", "0"], "SMAFA_KTH_SAMPLE_MIN_TILES": ["2", "8", "4096"]}
+            "SMAFA_ZONE_DIRECT": ["1", "1", "0"], "SMAFA_LADDER_PROBE": ["1", "1", "0"], "SMAFA_LAZY_FOLD": ["1", "1", "0"], "SMAFA_KTH_SAMPLE": ["16", "2", "4", "0"], "SMAFA_KTH_HIST_SEED": ["1", "1", "0"], "SMAFA_KTH_SAMPLE_MIN_TILES": ["2", "8", "4096"],
+            # the block index: built by the first big fixed-bound scan (mode 2) or on request below; forced onto dense stores too
+            "SMAFA_INDEX": ["1", "1", "2", "2", "0"], "SMAFA_INDEX_MIN_ROWS": ["1", "1000"], "SMAFA_INDEX_MAX_RUN": ["", "100000000"],
+            "SMAFA_INDEX_CAND": ["", "100"]}
 print("soak seed", seed0, flush=True)
 t_note = time.time()
 while time.time() < t_end:
@@ -38,7 +41,7 @@ while time.time() < t_end:
     n_letters = int(rng.choice([2, 4, 5] if alphabet == 0 else [2, 4, 20, 28]))
     L = int(rng.choice([1, 2, 7, 12, 20, 31, 32, 33, 60, 60, 60, 64, 65, 90, 96, 128, 129, 150, 200, 257]))
     n = int(rng.choice([1, 3, 255, 256, 257, 1000, 4097, 9000, 20000]))
-    nq = int(rng.choice([1, 2, 17, 64, 65, 300]))
+    nq = int(rng.choice([1, 2, 17, 64, 65, 300, 300]))
     if n <= 4097 and rng.random() < 0.12:
         nq = int(rng.choice([2100, 2600]))  # enough open queries for the near-hit ladder to be planned from a sample
     env = {k: str(rng.choice(v)) for k, v in SWITCHES.items()}
@@ -80,6 +83,8 @@ while time.time() < t_end:
         k = None if rng.random() < 0.4 else int(rng.choice([1, 1, 2, 3, 10, 400]))
         if D is None and k is None:
             D = int(rng.integers(0, min(L, 6) + 1))
+        if not handles and D is not None and D < min(L, 32) and L <= 128 and rng.random() < 0.3:
+            store.build_index(int(rng.integers(D, min(L, 32))))  # (a later append leaves it stale: the scan kernels answer then)
         got = store.scan(q, max_divergence=D, max_num_hits=k)
         full = oracle.scan_codes(s, q, L if D is None else D)
         want = full if k is None else expected_with_k(full, k)
