@@ -387,6 +387,9 @@ def compact_line(full: dict, full_path=None) -> dict:
 
     if full.get("indexed"):
         legs["idx"] = idx(full["indexed"])
+        bp = full["indexed"].get("besthit_planted")
+        if bp:  # best hit without a bound, planted queries: [wall ms scan kernels, wall ms with the index, verified]
+            legs["idx_besthit"] = [sig(g(bp, "scan_kernels", "wall_ms")), sig(g(bp, "with_index", "wall_ms")), bp.get("verified")]
     ha = full.get("host_api")
     if ha:
         legs["host_api"] = [sig(ha.get("ms_per_batch")), sig(ha.get("queries_per_s")), None, ha.get("rows_identical_to_device_launch")]
@@ -411,7 +414,8 @@ def compact_line(full: dict, full_path=None) -> dict:
                 "legs_key": "[ms (kernel; wall for besthit*/kth*/host_api; cfg4: wall s), query seqs/s (cfg4: records/s), "
                             "roofline frac, verified, ..]; unfiltered/boundN: [kernel ms, frac, verified]; kth*: 5th = kernel ms; "
                             "cfg4: 5th = scan kernel ms, 6th = CPU s extrapolated by pairs from a prefix; idx/cfgNi (opt-in block index on the same "
-                            "store): [kernel ms, query seqs/s, x the scan kernels, verified, build ms]",
+                            "store): [kernel ms, query seqs/s, x the scan kernels, verified, build ms]; idx_besthit (no bound, planted queries): "
+                            "[wall ms scan kernels, wall ms with the index, verified]",
                 "gathered_bytes_per_rank_per_step": full.get("gathered_bytes_per_rank_per_step"),
                 "run_s": full.get("run_s"), "skipped_for_time": [s_.get("leg") for s_ in full.get("skipped_for_time") or []],
                 "full_record": full_path})
@@ -505,6 +509,30 @@ class Bench:
                         "queries_per_s_wall": Q / (w_ms * 1e-3), "scan_kernel_ms": scan_kernel_ms,
                         "times_the_scan_kernels": scan_kernel_ms / k_ms if k_ms else None,
                         "launches_to_repay_the_build": build_call_ms / max(scan_kernel_ms - k_ms, 1e-9)})
+        store.drop_index()
+        return out
+
+    def indexed_besthit(self, store, queries, wide=11):
+        """`smafa query` without --max-divergence (best hit) on the planted queries, host code bytes in, ordered rows out: the scan
+        kernels' ladder against the same call with a block index built for bounds up to `wide` (it answers the ladder's first step)"""
+        out = {}
+        for name in ("scan_kernels", "with_index"):
+            info = store.build_index(wide) if name == "with_index" else None
+            store.scan(queries[:512], max_num_hits=1)
+            walls, kms, rows = [], [], None
+            for _ in range(3):
+                t = time.perf_counter()
+                rows = store.scan(queries, max_num_hits=1)
+                walls.append((time.perf_counter() - t) * 1e3)
+                kms.append(store.last_call_stats()["kernel_ms"])
+            out[name] = {"wall_ms": float(self.np.median(walls)), "kernel_ms": float(self.np.median(kms)),
+                         "queries_per_s_wall": len(queries) / (float(self.np.median(walls)) * 1e-3), "rows": int(len(rows))}
+            if info:
+                out[name]["index"] = {"blocks": info["blocks"], "bytes": info["bytes"], "build_ms_device": info["build_ms"],
+                                      "max_div_served": info["max_div_served"]}
+                out["verified"] = bool(rows.tobytes() == ref)
+            else:
+                ref = rows.tobytes()
         store.drop_index()
         return out
 
@@ -946,6 +974,9 @@ def main() -> int:
     if side_legs and args.mode == "scan" and args.prefilter and not args.no_index and in_budget("indexed", 6):
         indexed = B.indexed_leg(store, qset, D, Q, kernel_ms_avg)
         ok = ok and indexed["verified"]
+        if args.alphabet == "aa" and in_budget("indexed besthit", 4):
+            indexed["besthit_planted"] = B.indexed_besthit(store, my_q)
+            ok = ok and indexed["besthit_planted"]["verified"]
 
     # ---- stream mode: ONE query per pass — the HBM-bound form (north_star's literal "broadcast each query against
     #      all subjects"); three fractions of the 8 TB/s peak + the box's empirical read ceiling.

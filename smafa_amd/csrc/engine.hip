@@ -1370,6 +1370,25 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
         ladder.push_back(db->P >= 3 ? 30u : 16u);
     }
     const uint32_t limit = std::min<uint32_t>(max_div, db->L);
+    // A store with a current block index answers "every pair within d" for the largest bound d its blocks serve in a few
+    // microseconds per thousand queries: that fixed-bound scan goes first, in place of every tightening step at or below d
+    // (a query with k rows within d is finished exactly as after any other step).
+    uint32_t index_step = UINT32_MAX;  // position in the ladder of the step the index answers
+    if (k_mode >= 1 && n_queries > 64) {
+        uint8_t blocks[kIndexMaxBlocks];
+        uint32_t d = index_current(db) ? db->index.B : 0u;
+        while (d > 0 && !index_plan(db, d - 1u, (uint32_t)n_queries, blocks)) d--;
+        // (only where it replaces the ladder's first step: a lower bound than that finishes too few queries to pay for the
+        // extra round of compaction — nucleotides, 10M x 100 000 queries, index served up to 2: 27 -> 45 ms; profiles/r04_index.txt)
+        if (d > 0 && d - 1u < limit && !ladder.empty() && d - 1u >= ladder[0]) {
+            const uint32_t served = d - 1u;
+            std::vector<uint32_t> kept = {served};
+            for (uint32_t b : ladder)
+                if (b > served) kept.push_back(b);
+            ladder.swap(kept);
+            index_step = 0;
+        }
+    }
     std::vector<smafa_hit> done;      // rows of the finished queries (the caller's query numbers), ordered
     std::vector<uint32_t> ids;        // open queries: position in the current batch -> the caller's number (empty: same)
     std::vector<uint8_t> open_codes;  // ... and their code rows
@@ -1464,7 +1483,7 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
     // queries, 7 % of a k = 5 call).  Asked of every (n / 256)-th query first (0.1-0.2 ms): below a sixteenth of the sample finished,
     // the step is skipped and the later steps are planned right away.  Exact either way (a skipped step only moves queries to a
     // later, looser scan).
-    if (laddered && db->ladder_probe && n_queries >= 2048 && !ladder.empty() && limit > ladder[0]) {
+    if (laddered && db->ladder_probe && n_queries >= 2048 && !ladder.empty() && limit > ladder[0] && index_step != 0) {
         const uint32_t ns = 256, stride = (uint32_t)(n_queries / ns);
         std::vector<uint8_t> sample((size_t)ns * db->L);
         for (uint32_t i = 0; i < ns; i++) memcpy(&sample[(size_t)i * db->L], query_codes + (size_t)i * stride * db->L, db->L);
@@ -1503,13 +1522,17 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
         unsigned long long count = 0;
         // the step itself runs in the tightening mode (bound lowered to each query's k-th distance as the scan
         // proceeds), so on dense stores only the rows within the final bound come back, not every pair within it
-        rc = scan_range(db, qs, 0, cur_n, bound, k_mode, db->hits.as<smafa_hit>(), db->hits_cap(),
+        // (the index's step is a fixed-bound scan: every pair within the bound, from bound + 1 probes per query)
+        rc = scan_range(db, qs, 0, cur_n, bound, step == index_step ? 0u : k_mode, db->hits.as<smafa_hit>(), db->hits_cap(),
                         db->count.as<unsigned long long>());
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(&count, db->count.p, sizeof count, hipMemcpyDeviceToHost, db->stream));
         HIP_TRY(hipStreamSynchronize(db->stream));
         note_call_scan(db);
-        if (count > db->hits_cap()) break;  // too dense to look at: the full path decides
+        if (count > db->hits_cap()) {
+            if (step == index_step) continue;  // (more rows than the buffer holds: the tightening steps take over)
+            break;  // too dense to look at: the full path decides
+        }
         if (count == 0) {  // nobody within this bound: do the later steps pay?
             if (!planned && cur_n >= 2048 && step + 1 < ladder.size()) {
                 rc = plan_later_steps(step + 1);

@@ -67,6 +67,16 @@ def test_index_rows_equal_scan_rows_and_oracle(alphabet, n_letters, L):
         got_k = store.scan(q, max_divergence=D, max_num_hits=2)
         assert got_k.tobytes() == expected_with_k(want, 2).tobytes()
         probes += 1 if by_index else 0
+    # without a bound (`smafa query`'s default, best hit; the K branch): the index answers the ladder's first step — every pair
+    # within the largest bound it serves — and the scan kernels take the queries that step leaves open
+    few = q[:90]
+    full = oracle.scan_codes(s, few, L)
+    first_step = (min(32, L) - 1) // 6  # (the index takes the ladder's first step only where it serves at least that bound)
+    for k in (1, 3):
+        before = store.index_info()["probe_launches"]
+        got_k = store.scan(few, max_num_hits=k)
+        assert got_k.tobytes() == expected_with_k(full, k).tobytes(), (alphabet, L, k)
+        assert (store.index_info()["probe_launches"] > before) == (served is not None and served >= first_step)
     # bounds past the index, a handful of queries, the prefilter-off audit launch and mode 0: the scan kernels
     assert store.scan(q, max_divergence=7).tobytes() == oracle.scan_codes(s, q, 7).tobytes()
     assert "index_probe" not in store.last_scan_kernel()

@@ -47,4 +47,31 @@ for D in bounds:
     print("    index: %d blocks, %.0f MB, built in %.1f ms (call %.1f ms), longest run %d, candidates/query %.2f, served up to %s"
           % (info["blocks"], info["bytes"] / 1e6, info["build_ms"], build_wall, info["longest_run"], info["candidates_per_query"],
              info["max_div_served"]), flush=True)
+# the reference's default mode (best hit, no bound) and the K branch with an index built for bounds up to 11 (aa) / 5 (nt): the
+# index answers the ladder's first step
+if os.environ.get("INDEX_AB_BESTHIT", "1") != "0" and N <= 10_000_000:
+    far = synth.subjects(Q // 2, 60, alphabet, seed=9, dup_frac=0.0)
+    mixed = np.concatenate([q[: Q - Q // 2], far])
+    for label, qq in (("planted", q), ("half unrelated", mixed)):
+        for k in (1, 5):
+            res = {}
+            for mode in (0, 1):
+                if mode:
+                    info = store.build_index(11 if alphabet else 5)
+                else:
+                    store.drop_index()
+                store.scan(qq[:512], max_num_hits=k)
+                best = None
+                for _ in range(3):
+                    t = time.perf_counter()
+                    rows = store.scan(qq, max_num_hits=k)
+                    w = (time.perf_counter() - t) * 1e3
+                    st = store.last_call_stats()
+                    if best is None or w < best[0]:
+                        best = (w, st["kernel_ms"], st["scans"])
+                res[mode] = (rows.tobytes(), best)
+            print("%s N=%d Q=%d no bound, k=%d, %s queries: scan kernels wall %7.2f ms (kernels %7.2f, %d scans); with the index (%d blocks, "
+                  "served up to %s) wall %7.2f ms (kernels %7.2f, %d scans)  identical %s" %
+                  (shape, N, len(qq), k, label, res[0][1][0], res[0][1][1], res[0][1][2], info["blocks"], info["max_div_served"],
+                   res[1][1][0], res[1][1][1], res[1][1][2], res[0][0] == res[1][0]), flush=True)
 store.close()

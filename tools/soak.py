@@ -83,8 +83,9 @@ while time.time() < t_end:
         k = None if rng.random() < 0.4 else int(rng.choice([1, 1, 2, 3, 10, 400]))
         if D is None and k is None:
             D = int(rng.integers(0, min(L, 6) + 1))
-        if not handles and D is not None and D < min(L, 32) and L <= 128 and rng.random() < 0.3:
-            store.build_index(int(rng.integers(D, min(L, 32))))  # (a later append leaves it stale: the scan kernels answer then)
+        if not handles and (D is None or D < min(L, 32)) and L <= 128 and rng.random() < 0.3:
+            # (a later append leaves it stale: the scan kernels answer then; without a bound the index answers the ladder's first step)
+            store.build_index(int(rng.integers(0 if D is None else D, min(L, 32))))
         got = store.scan(q, max_divergence=D, max_num_hits=k)
         full = oracle.scan_codes(s, q, L if D is None else D)
         want = full if k is None else expected_with_k(full, k)
