@@ -174,7 +174,8 @@ struct smafa_db {
     double index_debt_ms = 0.0;     // mode 3: estimated kernel time of the eligible scans since the store last changed
     uint64_t index_debt_generation = 0;
     uint64_t index_max_run = 4096;  // a block whose longest run exceeds this is never probed (SMAFA_INDEX_MAX_RUN)
-    double index_cand_per_subject = 4e-6;  // candidates per query the probes may expect, per stored subject (SMAFA_INDEX_CAND)
+    double index_cand_per_subject = -1.0;  // candidates per query the probes may expect, per stored subject (SMAFA_INDEX_CAND;
+                                           // < 0: by the bound's class — index_cand_limit)
     uint64_t index_min_rows = 65536;  // mode 2 builds an index for stores of at least this many subjects (SMAFA_INDEX_MIN_ROWS)
     uint32_t index_probes = 0;      // launches answered by the index over the handle's life (smafa_index_info)
     size_t tile_words() const { return (size_t)P * W * kWaveTile; }
@@ -811,10 +812,20 @@ static int index_build(smafa_db *db, uint32_t blocks) {
     return SMAFA_OK;
 }
 
+// Candidates per query the probes of a scan with this bound may expect before the scan kernels are the better choice.
+// Measured on 10M-subject stores (profiles/r04_index.txt): a candidate costs 0.018 ns per stored vector of a subject (its
+// planes are gathered: 0.18 ns for 60 amino-acid columns, 0.07 ns for 2-bit nucleotides); a scanned subject costs the batched
+// kernels 1.7e-15 s per vector where the zone level and level 1 prune (aa bound 5: 1.7e-14 s per pair) and 8e-15 s and more
+// where only the folded levels reject (aa bounds 8..14: 0.8-1.1e-13 s).  Break-even is therefore subjects x 9e-5 / 4.4e-4
+// candidates; a third of that is allowed — queries are not spread like the store's own rows.
+static double index_cand_limit(const smafa_db *db, uint32_t thr0) {
+    const double per_subject = db->index_cand_per_subject >= 0.0 ? db->index_cand_per_subject
+                               : (db->W <= 4 && use_zone(db, thr0, prefilter_prunes(db, thr0))) ? 3e-5 : 1.5e-4;
+    return std::max(16.0, per_subject * (double)db->n);
+}
+
 // Which blocks a fixed-bound scan would probe, and whether that beats the scan kernels: bound + 1 blocks out of the usable
-// ones (longest run within index_max_run), the ones with the fewest expected candidates; the expected candidates per query
-// must stay within index_cand_per_subject x subjects (a candidate costs ~a dozen scattered 4-byte reads, a scanned subject
-// ~1.7e-14 s of a batched launch: profiles/r04_index.txt).
+// ones (longest run within index_max_run), the ones with the fewest expected candidates.
 static bool index_plan(const smafa_db *db, uint32_t thr0, uint32_t nq, uint8_t *probe_block) {
     const auto &ix = db->index;
     if (!db->index_mode || !db->use_filter || !index_current(db) || nq <= 64u || thr0 + 1u > ix.B) return false;
@@ -826,7 +837,7 @@ static bool index_plan(const smafa_db *db, uint32_t thr0, uint32_t nq, uint8_t *
     std::sort(usable, usable + nu, [&](uint8_t x, uint8_t y) { return ix.mean_run[x] < ix.mean_run[y] || (ix.mean_run[x] == ix.mean_run[y] && x < y); });
     double expected = 0.0;
     for (uint32_t j = 0; j <= thr0; j++) expected += ix.mean_run[usable[j]];
-    if (expected > std::max(16.0, db->index_cand_per_subject * (double)db->n)) return false;
+    if (expected > index_cand_limit(db, thr0)) return false;
     for (uint32_t j = 0; j <= thr0; j++) probe_block[j] = usable[j];
     return true;
 }
@@ -2005,12 +2016,12 @@ int smafa_index_info(const smafa_db *db, smafa_index_info_t *info) try {
     std::sort(runs.begin(), runs.end());
     info->usable_blocks = (uint32_t)runs.size();
     // the largest bound the index would answer for a big batch, and the candidates per query expected at it
-    const double limit = std::max(16.0, db->index_cand_per_subject * (double)db->n);
+    // (not every bound below it need be: the limit on candidates is wider where the scan kernels are in a slower form)
     double sum = 0.0;
     info->max_div_served = SMAFA_NONE;
     for (size_t j = 0; j < runs.size(); j++) {
         sum += runs[j];
-        if (sum > limit) break;
+        if (sum > index_cand_limit(db, (uint32_t)j)) continue;
         info->max_div_served = (uint32_t)j;
         info->candidates_per_query = sum;
     }
