@@ -238,6 +238,8 @@ int smafa_group_load(smafa_group **out, const int *devices, int ndev, const char
 int smafa_group_append(smafa_group *grp, const uint8_t *codes, uint64_t n);
 int smafa_group_scan_hits(smafa_group *grp, const uint8_t *query_codes, uint64_t n_queries, uint32_t max_div,
                           uint32_t max_num_hits, smafa_hit *out, uint64_t cap, uint64_t *n_out);
+/* smafa_db_build_index on every member, side by side (each replica keeps its own index on its device) */
+int smafa_group_build_index(smafa_group *grp, uint32_t max_divergence);
 int smafa_group_size(const smafa_group *grp);
 /* member `index` (borrowed; owned by the group): for smafa_db_info, the tuning knobs, or device-resident launches.
  * Rows are appended through smafa_group_append only (the replicas must stay identical); never destroy a member. */

@@ -29,7 +29,7 @@ EXPORTS = [
     "smafa_scan_each", "smafa_last_call_stats", "smafa_launch_device",
     "smafa_sync", "smafa_last_scan_ms", "smafa_last_scan_plan", "smafa_last_scan_kernel", "smafa_build_id", "smafa_hbm_read_probe", "smafa_set_query_block", "smafa_set_prefilter", "smafa_set_zone_level", "smafa_db_build_index", "smafa_db_drop_index", "smafa_index_info", "smafa_set_index", "smafa_select_rows", "smafa_write_rows",
     "smafa_dbfile_write", "smafa_dbfile_read", "smafa_fastx_load", "smafa_fastx_load_partial", "smafa_fastx_load_part", "smafa_free",
-    "smafa_group_create", "smafa_group_load", "smafa_group_append", "smafa_group_scan_hits", "smafa_group_size",
+    "smafa_group_create", "smafa_group_load", "smafa_group_append", "smafa_group_scan_hits", "smafa_group_build_index", "smafa_group_size",
     "smafa_group_member", "smafa_group_destroy",
     "smafa_qsession_open", "smafa_qsession_info", "smafa_qsession_scan_part", "smafa_qsession_write", "smafa_qsession_close",
     "smafa_makedb", "smafa_makedb_packed", "smafa_query", "smafa_query_multi", "smafa_cluster", "smafa_cluster_multi", "smafa_cluster_sharded", "smafa_count",
@@ -125,6 +125,7 @@ def lib() -> C.CDLL:
     l.smafa_group_load.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int, C.c_char_p]
     l.smafa_group_append.argtypes = [vp, vp, C.c_uint64]
     l.smafa_group_scan_hits.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]
+    l.smafa_group_build_index.argtypes = [vp, C.c_uint32]
     l.smafa_group_size.argtypes = [vp]
     l.smafa_group_member.argtypes = [vp, C.c_int]
     l.smafa_group_member.restype = vp

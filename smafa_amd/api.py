@@ -259,6 +259,16 @@ class SubjectGroup:
     def __len__(self) -> int:
         return lib().smafa_group_size(self._h)
 
+    def build_index(self, max_divergence: int) -> list:
+        """smafa_group_build_index: every replica builds its block index; -> per member smafa_index_info()"""
+        check(lib().smafa_group_build_index(self._h, int(max_divergence)))
+        out = []
+        for g in range(len(self)):
+            info = _lib.IndexInfo()
+            check(lib().smafa_index_info(lib().smafa_group_member(self._h, g), C.byref(info)))
+            out.append({k: getattr(info, k) for k, _ in _lib.IndexInfo._fields_})
+        return out
+
     def members(self):
         """per member: (smafa_db_info().device, device current at its last scan launch, launches off its device)"""
         out = []

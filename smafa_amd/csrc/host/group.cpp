@@ -149,6 +149,15 @@ int smafa_group_append(smafa_group *grp, const uint8_t *codes, uint64_t n) try {
     return smafa::exception_code("smafa_group_append");
 }
 
+int smafa_group_build_index(smafa_group *grp, uint32_t max_divergence) try {
+    if (!grp) return set_error(SMAFA_ERR_INVALID, "smafa_group_build_index: NULL handle");
+    if (grp->poisoned) return set_error(SMAFA_ERR_INVALID, "smafa_group_build_index: an append failed on some member; the replicas may differ");
+    // every replica builds its own (each on its device, side by side); a member whose build fails just keeps scanning
+    return group_on_every_handle(grp, [&](int g) { return smafa_db_build_index(grp->dbs[g], max_divergence); });
+} catch (...) {
+    return smafa::exception_code("smafa_group_build_index");
+}
+
 int smafa_group_size(const smafa_group *grp) { return grp ? (int)grp->dbs.size() : 0; }
 
 smafa_db *smafa_group_member(smafa_group *grp, int index) {

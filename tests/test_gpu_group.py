@@ -1,5 +1,6 @@
 """GPU tests of the round-3 entry points: the multi-device group (smafa_group_*), the one-pass-per-query launcher
 (smafa_scan_each) and the per-call totals (smafa_last_call_stats) — all through the C ABI, against the oracle."""
+import ctypes as C
 import os
 import subprocess
 import sys
@@ -9,7 +10,8 @@ import pytest
 
 import oracle
 import smafa_amd
-from smafa_amd import synth
+from smafa_amd import _lib, synth
+from smafa_amd._lib import lib
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -60,6 +62,15 @@ def test_group_rows_do_not_depend_on_the_number_of_handles(alphabet):
         # every member lives on ITS entry of `devices`, and its worker thread launched there: smafa_db_info().device, the HIP
         # device current on the launching thread, no launch off the handle's device (with more than one GPU visible the
         # members spread over them: the first real `--devices 0,1,..` run cannot silently put every replica on device 0)
+        assert g.members() == [(d, d, 0) for d in devs], (devs, g.members())
+        # every replica builds its own block index (smafa_group_build_index): the same rows from D + 1 probes per query
+        infos = g.build_index(D)
+        assert len(infos) == ndev and all(i["current"] == 1 and i["max_div_served"] == D for i in infos), infos
+        assert g.scan(qry, max_divergence=D).tobytes() == fixed.tobytes()
+        for m in range(ndev):
+            info = _lib.IndexInfo()
+            assert lib().smafa_index_info(lib().smafa_group_member(g._h, m), C.byref(info)) == 0
+            assert info.probe_launches == 1, (m, info.probe_launches)  # 1 001 queries in ndev blocks of more than 64
         assert g.members() == [(d, d, 0) for d in devs], (devs, g.members())
         g.close()
     assert got[1] == got[2] == got[3]
