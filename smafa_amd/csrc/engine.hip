@@ -3,6 +3,7 @@
 // selection, drivers) live in host/*.cpp.  No CPU fallback anywhere: without a HIP device every call
 // here fails.
 #include <hipcub/hipcub.hpp>
+#include <cmath>
 
 #include <algorithm>
 #include <atomic>
@@ -167,7 +168,7 @@ struct smafa_db {
         uint64_t max_run[kIndexMaxBlocks] = {0};  // longest run of equal keys of block b
         double mean_run[kIndexMaxBlocks] = {0};   // sum(run^2) / n: candidates a query drawn like the store's rows meets there
         double build_ms = 0.0;
-        DevBuf kp, dir, stats;
+        DevBuf kp, dir, stats, rows;
     } index;
     int index_mode = 1;             // 0: never probed; 1: probed where a built index pays; 2: also built by the first scan that could
                                     // use one; 3: ... built once such scans have cost what the build would (SMAFA_INDEX)
@@ -739,7 +740,7 @@ static bool index_current(const smafa_db *db) {
 
 static void index_drop(smafa_db *db) {
     db->index.valid = false;
-    for (DevBuf *b : {&db->index.kp, &db->index.dir, &db->index.stats}) b->release();
+    for (DevBuf *b : {&db->index.kp, &db->index.dir, &db->index.stats, &db->index.rows}) b->release();
 }
 
 // Build (or rebuild) the index with `blocks` blocks: serves every fixed bound up to blocks - 1.
@@ -761,7 +762,9 @@ static int index_build(smafa_db *db, uint32_t blocks) {
     uint32_t dir_bits = 8;
     while (dir_bits < 22 && (1ull << (dir_bits + 2)) < n) dir_bits++;
     const size_t dir_entries = ((size_t)1 << dir_bits) + 1;
+    const size_t row_bytes = (size_t)index_row_vectors((int)db->P, (int)db->W) * sizeof(uint4);
     rc = ix.kp.ensure((size_t)blocks * n * sizeof(uint2));
+    if (!rc) rc = ix.rows.ensure((size_t)n * row_bytes);
     if (!rc) rc = ix.dir.ensure((size_t)blocks * dir_entries * sizeof(uint32_t));
     if (!rc) rc = ix.stats.ensure((size_t)kIndexMaxBlocks * 2 * sizeof(unsigned long long));
     if (!rc) rc = db->keys_a.ensure((size_t)n * sizeof(uint32_t));
@@ -778,6 +781,8 @@ static int index_build(smafa_db *db, uint32_t blocks) {
     HIP_TRY(hipMemsetAsync(ix.stats.p, 0, (size_t)kIndexMaxBlocks * 2 * sizeof(unsigned long long), db->stream));
     const uint32_t grid = (n + 255u) / 256u;
     for (uint32_t b = 0; b <= blocks; b++) ix.col_begin[b] = (uint16_t)((uint64_t)b * db->L / blocks);
+    hipLaunchKernelGGL(index_rows_kernel, dim3(grid), dim3(256), 0, db->stream, db->d_planes, db->P, db->W, n, ix.rows.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
     for (uint32_t b = 0; b < blocks; b++) {
         hipLaunchKernelGGL(index_keys_kernel, dim3(grid), dim3(256), 0, db->stream, db->d_planes, db->P, db->W, n,
                            (uint32_t)ix.col_begin[b], (uint32_t)ix.col_begin[b + 1], ka, ia);
@@ -808,19 +813,27 @@ static int index_build(smafa_db *db, uint32_t blocks) {
     if (n > (1u << 20))
         for (DevBuf *b : {&db->keys_a, &db->keys_b, &db->idx_a, &db->idx_b, &db->sort_tmp}) b->release();
     log_line(2, "block index of %u rows: %u blocks, %.1f MB, built on the device in %.2f ms", n, blocks,
-             (double)(ix.kp.cap + ix.dir.cap) / 1e6, ix.build_ms);
+             (double)(ix.kp.cap + ix.dir.cap + ix.rows.cap) / 1e6, ix.build_ms);
     return SMAFA_OK;
 }
 
 // Candidates per query the probes of a scan with this bound may expect before the scan kernels are the better choice.
-// Measured on 10M-subject stores (profiles/r04_index.txt): a candidate costs 0.018 ns per stored vector of a subject (its
-// planes are gathered: 0.18 ns for 60 amino-acid columns, 0.07 ns for 2-bit nucleotides); a scanned subject costs the batched
-// kernels 1.7e-15 s per vector where the zone level and level 1 prune (aa bound 5: 1.7e-14 s per pair) and 8e-15 s and more
-// where only the folded levels reject (aa bounds 8..14: 0.8-1.1e-13 s).  Break-even is therefore subjects x 9e-5 / 4.4e-4
-// candidates; a third of that is allowed — queries are not spread like the store's own rows.
+// Measured on 10M-subject stores (profiles/r04_index.txt): a candidate costs ~0.025 ns (its row of the index's row-major copy,
+// one or two cache lines; gathered from the bit-planes it was 0.18 ns for 60 amino-acid columns).  A scanned subject costs the
+// batched kernels, per query: the zone kernel ~8e-14 s x the share of (query, tile) pairs that pass the zone level (level 1
+// over the tile for each of them: aa bound 5, share 0.2: 1.7e-14 s; bound 3: 3.7e-15; nt bound 3, share 0.025: 2.9e-15; bound 7:
+// 5.3e-14), the filter-plane-resident kernel at the bounds its folds reject 8e-14 s (aa 8..12, nt 9), the all-planes forms
+// 1.2e-13 s and more.  The candidates allowed are 0.45 of break-even — queries are not spread like the store's own rows — and an
+// underestimate of the scan only leaves a scan where the index would have been faster.
 static double index_cand_limit(const smafa_db *db, uint32_t thr0) {
-    const double per_subject = db->index_cand_per_subject >= 0.0 ? db->index_cand_per_subject
-                               : (db->W <= 4 && use_zone(db, thr0, prefilter_prunes(db, thr0))) ? 3e-5 : 1.5e-4;
+    double per_subject = db->index_cand_per_subject;
+    if (per_subject < 0.0) {
+        const bool prunes = prefilter_prunes(db, thr0);
+        const double scan_s = db->W <= 4 && use_zone(db, thr0, prunes) ? 8e-14 * std::min(1.0, std::max(0.02, zone_pass_share(db, thr0)))
+                              : fold_rejects(db, thr0) || prunes        ? 8e-14
+                                                                        : 1.2e-13;
+        per_subject = 0.45 * scan_s / 0.025e-9;
+    }
     return std::max(16.0, per_subject * (double)db->n);
 }
 
@@ -847,6 +860,7 @@ static int index_probe(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t 
     const auto &ix = db->index;
     IndexArgs x;
     x.kp = ix.kp.as<uint2>();
+    x.rows = ix.rows.as<uint4>();
     x.dir = ix.dir.as<uint32_t>();
     x.n = (uint32_t)ix.n;
     x.dir_bits = ix.dir_bits;
@@ -1873,7 +1887,7 @@ void smafa_db_destroy(smafa_db *db) {
                       &db->idx_a, &db->idx_b, &db->d_perm, &db->d_tab, &db->scratch_q.qrec,
                       &db->scratch_q.thr, &db->scratch_q.cnt, &db->scratch_q2.qrec, &db->scratch_q2.thr, &db->scratch_q2.cnt,
                       &db->scratch_q3.qrec, &db->scratch_q3.thr, &db->scratch_q3.cnt, &db->index.kp, &db->index.dir,
-                      &db->index.stats})
+                      &db->index.stats, &db->index.rows})
         b->release();
     if (db->each_graph) (void)hipGraphExecDestroy(db->each_graph);
     if (db->ev0) (void)hipEventDestroy(db->ev0);
@@ -2006,7 +2020,7 @@ int smafa_index_info(const smafa_db *db, smafa_index_info_t *info) try {
     if (!index_current(db)) return SMAFA_OK;
     info->current = 1;
     info->blocks = ix.B;
-    info->bytes = ix.kp.cap + ix.dir.cap;
+    info->bytes = ix.kp.cap + ix.dir.cap + ix.rows.cap;
     info->build_ms = ix.build_ms;
     std::vector<double> runs;
     for (uint32_t b = 0; b < ix.B; b++) {

@@ -27,6 +27,7 @@ constexpr int kIndexGroup = SMAFA_INDEX_GROUP;  // lanes that share one (query, 
 
 struct IndexArgs {
     const uint2 *kp;       // [B][n] sorted per block by key: {key, position in the packed store}
+    const uint4 *rows;     // [n][index_row_vectors(PS, W)]: every subject's plane words side by side (p * W + w), zero-padded
     const uint32_t *dir;   // [B][2^dir_bits + 1]: dir[b][j] = first slot whose key >> (32 - dir_bits) >= j
     uint32_t n;            // subjects indexed (= the store's)
     uint32_t dir_bits;
@@ -128,6 +129,21 @@ __global__ __launch_bounds__(256) void index_stats_kernel(const uint32_t *__rest
     }
 }
 
+// A candidate is compared from a ROW-MAJOR copy of the store the index keeps for itself: the bit-plane layout spreads a subject
+// over PS * W arrays (ten 4-byte gathers from ten cache lines for 60 amino-acid columns); side by side they are 1-2 lines and
+// three 16-byte loads (bound 14 on 10M aa rows, 950 candidates per query: 1.86 -> see profiles/r04_index.txt).
+__host__ __device__ constexpr int index_row_vectors(int ps, int w) { return (ps * w + 3) / 4; }
+
+__global__ __launch_bounds__(256) void index_rows_kernel(const uint32_t *__restrict__ planes, uint32_t PS, uint32_t W, uint32_t n,
+                                                         uint32_t *__restrict__ rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *t = planes + (size_t)(i >> 8) * ((size_t)PS * W * 256) + (i & 255u);
+    const uint32_t words = PS * W, stride = ((words + 3u) / 4u) * 4u;
+    uint32_t *r = rows + (size_t)i * stride;
+    for (uint32_t j = 0; j < stride; j++) r[j] = j < words ? t[(size_t)j * 256] : 0u;
+}
+
 // One group of kIndexGroup lanes per (query, probe).  Rows are parked in LDS and written out once per workgroup: every row
 // taking its own slot from the list's counter costs ~12 ns of serialised atomics on one address — 5 555 rows of the metric's
 // launch were 55 of the kernel's 65 us (profiles/r04_index.txt).
@@ -172,7 +188,7 @@ __global__ __launch_bounds__(kIndexWg) void index_probe_kernel(const uint32_t *_
             return v;
         });
         // Four dependent memory round trips per probe: [probe columns, query record] -> directory -> (key, position) slots ->
-        // the candidate's planes.  The directory slot holds every key with the probe key's top dir_bits bits (~2-3 entries):
+        // the candidate's row.  The directory slot holds every key with the probe key's top dir_bits bits (~2-3 entries):
         // the group's lanes read them side by side, no search.
         const uint2 *kp = x.kp + (size_t)b * x.n;
         const uint32_t *dir = x.dir + (size_t)b * ((1u << x.dir_bits) + 1u);
@@ -183,14 +199,20 @@ __global__ __launch_bounds__(kIndexWg) void index_probe_kernel(const uint32_t *_
             if (e.x > key) break;  // sorted: nothing further on in this lane's stride can match
             if (e.x != key) continue;
             const uint32_t at = e.y;
-            const uint32_t *t = planes + (size_t)(at >> 8) * ((size_t)PS * W * 256) + (at & 255u);
+            constexpr int RV = index_row_vectors(PS, W);
+            uint32_t sw[RV * 4];
+#pragma unroll
+            for (int v = 0; v < RV; v++) {
+                const uint4 x4 = x.rows[(size_t)at * RV + v];
+                sw[v * 4 + 0] = x4.x, sw[v * 4 + 1] = x4.y, sw[v * 4 + 2] = x4.z, sw[v * 4 + 3] = x4.w;
+            }
             uint32_t m[kIndexMaxWords] = {0u, 0u, 0u, 0u};
             uint32_t dist = 0;
 #pragma unroll
             for (int w = 0; w < W; w++) {
                 uint32_t mw = extra[w];
 #pragma unroll
-                for (int p = 0; p < PS; p++) mw = or_xor(mw, t[(size_t)(p * W + w) * 256], qw[p * W + w]);
+                for (int p = 0; p < PS; p++) mw = or_xor(mw, sw[p * W + w], qw[p * W + w]);
                 m[w] = mw;
                 dist += (uint32_t)__builtin_popcount(mw);
             }
