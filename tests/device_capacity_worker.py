@@ -52,6 +52,33 @@ def main():
         assert int(d_count.item()) >= nq
         qset.close()
     store.close()
+    # the same contract when the launch is answered from the block index: 128 distinct rows x 64 copies, 100 of them as queries —
+    # 6 400 rows, far more per workgroup than its LDS stage parks (the rest goes straight to the list)
+    os.environ["SMAFA_INDEX_CAND"] = "1"  # (runs of 64 equal keys: forced past the limit on expected candidates)
+    distinct = rng.integers(0, 4, size=(128, L), dtype=np.uint8)
+    s = np.repeat(distinct, 64, axis=0)[rng.permutation(128 * 64)]
+    q = distinct[:100].copy()
+    store = smafa_amd.SubjectStore(L, 0)
+    store.push(s)
+    assert store.build_index(2)["max_div_served"] == 2
+    qset = smafa_amd.QuerySet(store, q)
+    want = oracle.scan_codes(s, q, 2)
+    total = len(want)
+    assert total >= 6400
+    keys = set(zip(want["query"].tolist(), want["subject"].tolist(), want["dist"].tolist()))
+    for cap in (total, total - 1, 700, 1, 0):
+        d_hits = torch.full((max(cap, 1) * 3 + 3,), -1, dtype=torch.int32, device="cuda")
+        for _ in range(2):
+            store.scan_launch(qset, 2, None, d_hits.data_ptr() if cap else 0, cap, d_count.data_ptr())
+            store.sync()
+            assert "index_probe" in store.last_scan_kernel(), store.last_scan_kernel()
+            assert int(d_count.item()) == total, (cap, int(d_count.item()), total)
+        rows = d_hits[: 3 * cap].cpu().numpy().view(np.uint32).reshape(-1, 3)
+        assert (d_hits[3 * cap:].cpu().numpy() == -1).all(), "wrote past the capacity"
+        mine = list(zip(rows[:, 0].tolist(), rows[:, 1].tolist(), rows[:, 2].tolist()))
+        assert len(set(mine)) == len(mine) == cap and set(mine) <= keys, cap
+    qset.close()
+    store.close()
     print("device capacity ok")
 
 
