@@ -377,6 +377,9 @@ def compact_line(full: dict, full_path=None) -> dict:
         nm = rel.get("besthit_novel_members")
         if nm:
             legs["besthit_novel"] = [sig(nm.get("wall_ms")), sig(nm.get("queries_per_s_wall")), None, nm.get("verified")]
+            if nm.get("indexed"):  # [wall ms scan kernels, wall ms with a 15-block index, verified]
+                legs["idx_novel"] = [sig(g(nm, "indexed", "scan_kernels", "wall_ms")), sig(g(nm, "indexed", "with_index", "wall_ms")),
+                                     nm["indexed"].get("verified")]
     for name, leg in (full.get("kth") or {}).items():
         if isinstance(leg, dict):
             legs[name] = [sig(leg.get("wall_ms")), sig(leg.get("queries_per_s_wall")), sig(g(leg, "roofline", "frac")),
@@ -414,8 +417,8 @@ def compact_line(full: dict, full_path=None) -> dict:
                 "legs_key": "[ms (kernel; wall for besthit*/kth*/host_api; cfg4: wall s), query seqs/s (cfg4: records/s), "
                             "roofline frac, verified, ..]; unfiltered/boundN: [kernel ms, frac, verified]; kth*: 5th = kernel ms; "
                             "cfg4: 5th = scan kernel ms, 6th = CPU s extrapolated by pairs from a prefix; idx/cfgNi (opt-in block index on the same "
-                            "store): [kernel ms, query seqs/s, x the scan kernels, verified, build ms]; idx_besthit (no bound, planted queries): "
-                            "[wall ms scan kernels, wall ms with the index, verified]",
+                            "store): [kernel ms, query seqs/s, x the scan kernels, verified, build ms]; idx_besthit / idx_novel (no bound; planted queries / novel family "
+                            "members): [wall ms scan kernels, wall ms with the index, verified]",
                 "gathered_bytes_per_rank_per_step": full.get("gathered_bytes_per_rank_per_step"),
                 "run_s": full.get("run_s"), "skipped_for_time": [s_.get("leg") for s_ in full.get("skipped_for_time") or []],
                 "full_record": full_path})
@@ -1205,6 +1208,10 @@ def main() -> int:
                            "note": "best hit without a bound for %d novel family members (family roots re-diverged by 10-25 %%, "
                                    "not in the store) against the related store: the near-hit ladder answers them" % Q}
         r_ok = r_ok and nov_ok
+        if not args.no_index and args.alphabet == "aa" and in_budget("indexed besthit novel", 5):
+            # ... and with a block index wide enough for most of them (bounds up to 14: 15 blocks of 4 columns)
+            besthit_related["indexed"] = B.indexed_besthit(r_store, novel, wide=14)
+            r_ok = r_ok and besthit_related["indexed"]["verified"]
         related = {"kernel": r_kernel, "kernel_ms": r_med, "queries_per_s": Q / (r_med * 1e-3), "rows": n_r,
                    "besthit_novel_members": besthit_related,
                    "slowdown_vs_uniform": r_med / kernel_ms_avg, "verified": bool(r_ok),

@@ -174,6 +174,7 @@ struct smafa_db {
                                     // use one; 3: ... built once such scans have cost what the build would (SMAFA_INDEX)
     double index_debt_ms = 0.0;     // mode 3: estimated kernel time of the eligible scans since the store last changed
     uint64_t index_debt_generation = 0;
+    uint64_t index_failed_generation = 0;  // generation + 1 of the store whose automatic build failed (0: none)
     uint64_t index_max_run = 4096;  // a block whose longest run exceeds this is never probed (SMAFA_INDEX_MAX_RUN)
     double index_cand_per_subject = -1.0;  // candidates per query the probes may expect, per stored subject (SMAFA_INDEX_CAND;
                                            // < 0: by the bound's class — index_cand_limit)
@@ -1019,9 +1020,14 @@ static int scan_range(smafa_db *db, smafa_qset *qs, uint32_t q_begin, uint32_t q
                 db->index_debt_ms += (double)nq * (double)db->n * (double)(db->P * db->W) * 1.7e-12;
                 build = db->index_debt_ms >= 0.3 + (double)(thr0 + 1u) * (double)db->n * 1.0e-7;
             }
-            if (build) {
-                int irc = index_build(db, thr0 + 1u);
-                if (irc) return irc;
+            if (build && db->index_failed_generation != db->generation + 1u) {
+                // (a build that fails — no room for another 8 B x blocks + a row copy per subject — is not the scan's failure:
+                // the scan kernels answer, and the automatic modes do not try again until the store changes)
+                if (index_build(db, thr0 + 1u) != SMAFA_OK) {
+                    log_line(1, "block index not built (%s): scanning as before", smafa_last_error());
+                    index_drop(db);
+                    db->index_failed_generation = db->generation + 1u;
+                }
             }
         }
         uint8_t probe_block[kIndexMaxBlocks];

@@ -26,7 +26,9 @@ def full_record():
     full["stream"]["fetched_over_plane"] = 1.0002761030351117
     ix = {"max_divergence": 5, "served": True, "kernel": "smafa::index_probe_kernel<5, 5, 2>", "kernel_ms": 0.0671234, "verified": True,
           "queries_per_s": 148981234.5, "times_the_scan_kernels": 25.3456, "index": {"blocks": 6, "build_ms_call": 25.41234}}
-    full["indexed"] = ix
+    full["indexed"] = dict(ix, besthit_planted={"scan_kernels": {"wall_ms": 8.31234}, "with_index": {"wall_ms": 0.36789}, "verified": True})
+    full["related"]["besthit_novel_members"]["indexed"] = {"scan_kernels": {"wall_ms": 16.31234}, "with_index": {"wall_ms": 5.6789},
+                                                           "verified": True}
     for name in full["configs"]:
         if "cluster" not in name:
             full["configs"][name]["indexed"] = dict(ix)
@@ -59,6 +61,7 @@ def test_compact_line_fits_and_keeps_the_contract():
                  "kth5", "kth50", "kth5_d5", "kth50_d5", "cfg1", "cfg2", "cfg2N", "cfg3", "cfg4"):
         assert name in legs and legs[name][0] > 0, name
     assert legs["cfg2"][3] is True and legs["kth50"][3] is True and legs["cfg4"][5] > 1000
+    assert legs["idx_besthit"] == [8.312, 0.3679, True] and legs["idx_novel"] == [16.31, 5.679, True]
     for name in ("idx", "cfg1i", "cfg2i", "cfg2Ni", "cfg3i"):
         assert legs[name] == [0.06712, 149000000.0, 25.3, True, 25.4], (name, legs[name])
     assert out["full_record"] == "gpurun_out/bench_full.json" and out["skipped_for_time"] == ["configs[4] cluster"]
