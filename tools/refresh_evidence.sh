@@ -1,5 +1,5 @@
 #!/bin/bash
-# On the GPU box, after ANY change to kernels.hip.h / engine.hip (the build id changes): collect the counter records of
+# On the GPU box, after ANY change to kernels.hip.h / index.hip.h / engine.hip (the build id changes): collect the counter records of
 # every workload bench.py looks up (tools/collect_pmc.py: rocprofv3 --pmc passes of the same bench command, program directly
 # after `--`), assemble profiles/r04_pmc.json, take the bench line of record with it in place, and leave everything under
 # gpurun_out/evidence/ in the names profiles/ uses (copy them over afterwards).  Three parts, in one call (about six minutes)
