@@ -46,7 +46,7 @@ def test_index_rows_equal_scan_rows_and_oracle(alphabet, n_letters, L):
     n = 70000
     s = rng.integers(0, n_letters, size=(n, L), dtype=np.uint8)
     s[5000:5040] = s[4999]  # identical subjects: one run of 41 equal keys in every block
-    q = np.concatenate([queries_from(rng, s, 400, n_letters, 7), rng.integers(0, n_letters, size=(100, L), dtype=np.uint8),
+    q = np.concatenate([queries_from(rng, s, 250, n_letters, 7), rng.integers(0, n_letters, size=(50, L), dtype=np.uint8),
                         s[4999:5000]])
     store = smafa_amd.SubjectStore(L, alphabet)
     store.push(s)
@@ -57,7 +57,7 @@ def test_index_rows_equal_scan_rows_and_oracle(alphabet, n_letters, L):
     if L >= 60:
         assert served == 6 and info["usable_blocks"] == 7, info
     probes = 0
-    for D in (0, 1, 3, 5, 6):
+    for D in (0, 3, 5, 6):
         want = oracle.scan_codes(s, q, D)
         got = store.scan(q, max_divergence=D)
         by_index = store.last_scan_kernel() == probe_name(store)
