@@ -438,6 +438,11 @@ int smafa_query_multi(const char *db_path, const char *query_fasta, uint32_t max
             if (!rc) rc = smafa_group_append(group.g, codes, n);
         }
         if (rc) return rc;
+        // A query file is scanned chunk by chunk against the same resident store: let every replica decide by itself when its block
+        // index has paid for itself (rent or buy, smafa_set_index 3 — a run of a few thousand queries never builds one; a million
+        // queries against 50M subjects build it during the first chunk).  An explicit SMAFA_INDEX wins.
+        if (!getenv("SMAFA_INDEX"))
+            for (int g = 0; g < ndev; g++) (void)smafa_set_index(group_member(group.g, g), 3);
         log_line(2, "subject store packed into HBM on %d handle(s) in %.2f s", ndev, now_seconds() - t0);
     }
     // fn(g) for every block of a chunk on its own host thread (without a store: nothing to scan, one thread)

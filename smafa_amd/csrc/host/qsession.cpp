@@ -103,6 +103,7 @@ int smafa_qsession_open(smafa_qsession **out, const char *db_path, int device) t
             if (rc) return fail(rc);
         }
     }
+    if (s->db && !getenv("SMAFA_INDEX")) (void)smafa_set_index(s->db, 3);  // (as smafa_query_multi: rent or buy)
     s->subjects.codes = s->codes;
     s->subjects.packed = s->packed ? &s->pk : nullptr;
     s->subjects.L = s->L;

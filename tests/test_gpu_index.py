@@ -3,12 +3,14 @@ bound + 1 probes per query must give the rows of the scan kernels and of the ora
 looks like (duplicates, families, letters the store has never seen, several appends) — and must step aside by itself
 where the store's blocks are not selective or the index is stale.  Everything through the C ABI."""
 import os
+import subprocess
 
 import numpy as np
 import pytest
 
 import oracle
 import smafa_amd
+from smafa_amd import _lib
 from test_gpu_layout import expected_with_k, queries_from, skewed_store
 
 pytestmark = pytest.mark.gpu
@@ -212,3 +214,29 @@ def test_index_arguments():
         store.build_index(40)
     assert store.build_index(19)["blocks"] == 20
     store.close()
+
+
+def test_product_cli_answers_from_the_index_when_told_to(index_env, tmp_path):
+    """`smafa query` lets each store decide when its block index has paid for itself (rent or buy: never at this size); an explicit
+    SMAFA_INDEX wins — here mode 2, an index at the first chunk of queries: the same bytes as the oracle CLI, and the log says so"""
+    rng = np.random.default_rng(11)
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    s = letters[rng.integers(0, 4, size=(30000, 60))]
+    s[7] = s[3]
+    q = s[rng.integers(0, len(s), size=400)].copy()
+    for r in q:
+        for _ in range(int(rng.integers(0, 6))):
+            r[rng.integers(0, 60)] = letters[rng.integers(0, 5)]
+    sf, qf, db = str(tmp_path / "s.fna"), str(tmp_path / "q.fna"), str(tmp_path / "db")
+    oracle.write_fasta(sf, [bytes(r) for r in s])
+    oracle.write_fasta(qf, [bytes(r) for r in q])
+    assert subprocess.run([_lib.CLI_PATH, "makedb", "-i", sf, "-d", db], capture_output=True).returncode == 0
+    for flags in (["--max-divergence", "3"], ["--max-divergence", "2", "--max-num-hits", "4"]):
+        want = oracle.run_cli("query", "-d", db, "-q", qf, *flags)
+        plain = subprocess.run([_lib.CLI_PATH, "query", "-d", db, "-q", qf, "-v", *flags], capture_output=True, text=True)
+        assert plain.returncode == want.returncode == 0 and plain.stdout == want.stdout
+        assert "block index" not in plain.stderr  # rent or buy: 400 queries x 30 000 subjects never pay for one
+        env = dict(os.environ, SMAFA_INDEX="2", SMAFA_INDEX_MIN_ROWS="1")
+        forced = subprocess.run([_lib.CLI_PATH, "query", "-d", db, "-q", qf, "-v", *flags], capture_output=True, text=True, env=env)
+        assert forced.returncode == 0 and forced.stdout == want.stdout, flags
+        assert "block index of 30000 rows" in forced.stderr, forced.stderr[-400:]
