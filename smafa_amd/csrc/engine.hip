@@ -1404,6 +1404,29 @@ int scan_to_host(smafa_db *db, const uint8_t *query_codes, uint64_t n_queries, u
     // A store with a current block index answers "every pair within d" for the largest bound d its blocks serve in a few
     // microseconds per thousand queries: that fixed-bound scan goes first, in place of every tightening step at or below d
     // (a query with k rows within d is finished exactly as after any other step).
+    // Rent or buy (mode 3 — what `smafa query` sets) for calls WITHOUT a usable bound too: the ladder and the loose path cost the
+    // scan kernels ~1.6e-11 ms per pair and stored vector (10 000 queries x 10M aa: 16-19 ms, profiles/r04_bench_full.json); once
+    // such calls have cost what an index for the ladder's first steps would, it is built — blocks as narrow as the store's size
+    // leaves selective (~log2(n) - 2 bits of letters per block: 4 aa columns, 10 nucleotides at 10M subjects), so that it serves
+    // the widest bounds it can (aa: up to 14).  Only where that index would take at least the ladder's first step.
+    if (db->index_mode == 3 && k_mode >= 1 && n_queries > 64 && db->use_filter && db->lazy && db->two_phase && !ladder.empty() &&
+        limit > ladder[0] && db->W <= (uint32_t)kIndexMaxWords && db->n >= db->index_min_rows && db->n < (1ull << 31) &&
+        db->index_failed_generation != db->generation + 1u) {
+        const double letter_bits = db->alphabet == SMAFA_ALPHABET_AA ? 4.3 : db->P == 2 ? 2.0 : 2.3;
+        const uint32_t width = (uint32_t)std::max(2.0, std::floor((std::log2((double)db->n) - 2.0) / letter_bits));
+        const uint32_t want = std::min<uint32_t>((uint32_t)kIndexMaxBlocks, db->L / width);
+        if (want >= ladder[0] + 1u && (!index_current(db) || db->index.B < want)) {
+            if (db->index_debt_generation != db->generation) db->index_debt_ms = 0.0, db->index_debt_generation = db->generation;
+            db->index_debt_ms += (double)n_queries * (double)db->n * (double)(db->P * db->W) * 1.6e-11;
+            if (db->index_debt_ms >= 0.3 + (double)want * (double)db->n * 1.0e-7) {
+                if (index_build(db, want) != SMAFA_OK) {
+                    log_line(1, "block index not built (%s): scanning as before", smafa_last_error());
+                    index_drop(db);
+                    db->index_failed_generation = db->generation + 1u;
+                }
+            }
+        }
+    }
     uint32_t index_step = UINT32_MAX;  // position in the ladder of the step the index answers
     if (k_mode >= 1 && n_queries > 64) {
         uint8_t blocks[kIndexMaxBlocks];

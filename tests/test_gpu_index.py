@@ -150,6 +150,33 @@ def test_stale_index_steps_aside_and_rebuilds(index_env):
     store.close()
 
 
+def test_rent_or_buy_without_a_bound(index_env):
+    """mode 3 (what `smafa query` sets) for the reference's default mode — best hit, no bound: the ladder's scans are charged at the
+    scan kernels' rate and an index for the ladder's first steps is built once they have cost what it would; rows never change"""
+    index_env["SMAFA_INDEX"] = "3"
+    index_env["SMAFA_INDEX_MIN_ROWS"] = "1"
+    rng = np.random.default_rng(5)
+    s = rng.integers(0, 20, size=(80000, 60), dtype=np.uint8)
+    q = queries_from(rng, s, 300, 20, 9)
+    full = oracle.scan_codes(s, q, 60)
+    want = {k: expected_with_k(full, k).tobytes() for k in (1, 2)}
+    store = smafa_amd.SubjectStore(60, 1)
+    store.push(s)
+    calls = 0
+    while store.index_info()["probe_launches"] == 0:
+        k = 1 + calls % 2
+        assert store.scan(q, max_num_hits=k).tobytes() == want[k], (calls, k)
+        calls += 1
+        assert calls < 400
+    # 300 queries x 80 000 subjects x 10 vectors x 1.6e-11 ms = 3.8e-3 ms per call against 0.3 + 20 blocks x 80 000 x 1e-7 = 0.46 ms
+    info = store.index_info()
+    assert 110 < calls < 130 and info["blocks"] == 20 and info["current"] == 1, (calls, info)
+    for k in (1, 2):
+        assert store.scan(q, max_num_hits=k).tobytes() == want[k]
+    assert store.index_info()["probe_launches"] >= 3
+    store.close()
+
+
 def test_dense_and_low_complexity_stores_are_left_to_the_scan_kernels_unless_forced(index_env):
     rng = np.random.default_rng(99)
     L = 60
